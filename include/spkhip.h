@@ -1,0 +1,133 @@
+/* libspkhip - C ABI of the MI355X (gfx950) speaker-embedding hot path.
+ *
+ * Drop-in boundary: the reference (ZihanLiao/pytorch-kaldi-resnet) has no native
+ * layer; its seam is the torch.nn.Module protocol of NeuralSpeakerModel (scripts/model.py:334-432) as
+ * driven by scripts/train_resnet.py:304-328 and scripts/decode.py:185-208.  Every torch op on that path
+ * maps to one export below; the Python mirror of NeuralSpeakerModel binds them with ctypes
+ * (pytorch-kaldi-resnet_amd/hip.py).  Each export cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
+ *   - the caller owns every buffer, including workspaces; the library never allocates device memory
+ *     and keeps no pointer across calls
+ *   - every call is an asynchronous launch on `stream` (a hipStream_t) and never synchronises
+ *   - return value: 0 = ok, < 0 = invalid argument (see spk_last_error), > 0 = hipError_t of the launch
+ *   - activations are NHWC fp32: [B][H = mel bins][W = frames][C]; the network input is [B][F][T]
+ *     (reference layout, scripts/datasets.py:68, scripts/model.py:247) which is NHWC with C = 1
+ *   - arithmetic is fp32 throughout (MFMA v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain)
+ */
+#ifndef SPKHIP_H
+#define SPKHIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int spk_version(void);
+const char* spk_last_error(void);
+
+/* flags for the fused input transform / epilogue of the convolutions */
+#define SPK_IN_AFFINE_RELU 1 /* input tile = max(in*in_scale[c] + in_shift[c], 0): BN+ReLU of the producer, fused */
+#define SPK_EPI_AFFINE 2     /* out = acc*epi_scale[c] + epi_shift[c]   (eval-mode BN folded into the conv) */
+#define SPK_EPI_ADD 4        /* out += epi_add[same index]              (residual add / gradient accumulation) */
+#define SPK_EPI_RELU 8       /* out = max(out, 0) */
+#define SPK_EPI_STATS 16     /* stats[pixel_tile][c] = (sum, sumsq) of the stored values (train-mode BN) */
+
+/* ---- convolutions --------------------------------------------------------------------------------- */
+
+/* nn.Conv2d weight [Cout][Cin][KH][KW] (scripts/model.py:12-15,105-110,233-234) -> MFMA fragment order
+ * [tap][K/8][N/32][64][4]; transpose = 0 for the forward conv (K = Cin), 1 for its data gradient (K = Cout). */
+int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
+
+/* Implicit-GEMM convolution described by a tap table; replaces F.conv2d forward (scripts/model.py:51,56,
+ * 118,122,126,58-59) and, with a transposed pack and mirrored taps, its data gradient (autograd of the same,
+ * scripts/train_resnet.py:327).  Logical output pixel (oy,ox) of an OH x OW grid reads input pixel
+ * (oy*IS + tap_dy[t], ox*IS + tap_dx[t]) with weight tap tap_w[t] and is stored at (oy*OS + ooy, ox*OS + oox)
+ * of the physical [B][OHf][OWf][Cout] output.  TH x TW = pixel region per block (<= 128*MT pixels),
+ * MT in 1..4 m-tiles per wave, NT in {1,2,4} 32-channel n-tiles per block.
+ * stats (EPI_STATS): [B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats. */
+int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
+                  const float* epi_scale, const float* epi_shift, const float* epi_add, float* stats, int B, int IH,
+                  int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
+                  int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
+                  int TW, int MT, int NT, int flags, void* stream);
+
+/* Weight gradient of a 3x3 (pad 1) or 1x1 (pad 0) conv at stride 1 or 2 (autograd of nn.Conv2d).
+ * x: conv input [B][IH][IW][Cin] (optionally raw + fused BN/ReLU via in_scale/in_shift and SPK_IN_AFFINE_RELU),
+ * dy: gradient of the raw conv output [B][OH][OW][Cout]; dw: OIHW [Cout][Cin][k][k].
+ * partial: workspace of spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout) bytes. TW must be even. */
+size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
+int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
+                   const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,
+                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, void* stream);
+
+/* Stem Conv2d(1,32,3,1,1,bias=False) (scripts/model.py:210,249): x [B][F][T] -> out [B][F][T][32];
+ * stats (EPI_STATS): [spk_stem_fwd_blocks()][32][2]. */
+int spk_stem_fwd_blocks(int B, int F, int T);
+int spk_stem_conv_fwd(const float* x, const float* w, float* out, float* stats, const float* epi_scale,
+                      const float* epi_shift, int B, int F, int T, int flags, void* stream);
+/* its weight gradient; partial: [spk_stem_wgrad_blocks()][32*9] floats */
+int spk_stem_wgrad_blocks(int B, int F, int T);
+int spk_stem_conv_wgrad(const float* x, const float* draw, float* dw, float* partial, int B, int F, int T,
+                        int accumulate, void* stream);
+
+/* ---- batch normalisation (nn.BatchNorm2d/1d, scripts/model.py:41,44,212,235,361) ------------------- */
+/* x viewed as [N][C], C a power of two in [4,1024] */
+int spk_bn_stats_blocks(long long N, int C);
+int spk_bn_stats_partial(const float* x, float* partial /*[blocks][C][2]*/, long long N, int C, void* stream);
+/* partial -> batch mean / invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated with
+ * momentum and unbiased variance, *num_batches_tracked += 1 (pass NULLs to skip the running update) */
+int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* invstd,
+                    float* scale, float* shift, float momentum, float eps, void* stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float* scale, float* shift, int C, float eps, void* stream);
+/* out = [relu](raw*scale + shift [+ res | + res*res_scale + res_shift])  (BasicBlock tail, scripts/model.py:58-62) */
+int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
+                 const float* res_shift, float* out, long long N, int C, int relu, void* stream);
+/* backward; mask_mode 0: dz = dy, 1: dz = dy*(act > 0), 2: dz = dy*(raw*scale+shift > 0) */
+int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
+                      void* stream);
+int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, void* stream);
+int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,
+                     int C, int mask_mode, void* stream);
+
+/* ---- statistics pooling (StatsPooling, scripts/model.py:435-457; mode 0 = 'mean', 1 = 'mean+std') -------- */
+int spk_stats_pool_fwd(const float* x /*[B][H][W][C]*/, float* out /*[B][C*H*(1+mode)]*/, int B, int H, int W, int C,
+                       int mode, void* stream);
+int spk_stats_pool_bwd(const float* x, const float* gout, float* dx, int B, int H, int W, int C, int mode, void* stream);
+
+/* ---- GEMM (fc1 = nn.Linear(5120,256) scripts/model.py:357; cosine F.linear :485; their gradients) ------ */
+int spk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long long sam,
+                 long long sak, long long sbk, long long sbn, long long ldc, float alpha, int accumulate, void* stream);
+int spk_colsum(const float* dy, float* db, int M, int N, int accumulate, void* stream);
+
+/* ---- heads ------------------------------------------------------------------------------------------- */
+/* F.normalize rows (scripts/model.py:485) and its gradient */
+int spk_l2norm_fwd(const float* x, float* y, float* inv_norm, int R, int D, float eps, void* stream);
+int spk_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int R, int D, float eps,
+                   int accumulate, void* stream);
+/* AAM margin on the label column + scale (scripts/model.py:487-499) and its gradient */
+int spk_aam_margin_fwd(const float* cosv, const long long* label, float* logits, int B, int S, float m, float s,
+                       void* stream);
+int spk_aam_margin_bwd(const float* cosv, const long long* label, const float* dlogits, float* dcos, int B, int S,
+                       float m, float s, void* stream);
+/* nn.CrossEntropyLoss rows (scripts/train_resnet.py:201,317): loss_row, dlogits = (softmax-onehot)*grad_scale,
+ * rank[b] = #{j: logit_j > logit_label} (scripts/accuracy.py:4-16: correct@k <=> rank < k) */
+int spk_softmax_ce(const float* logits, const long long* label, float* loss_row, float* dlogits, int* rank, int B, int S,
+                   float grad_scale, void* stream);
+int spk_mean(const float* v, float* out, int n, void* stream);
+int spk_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
+
+/* ---- optimizer (torch.optim.SGD, scripts/train_resnet.py:203-205,328) ------------------------------------ */
+int spk_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay,
+                 float grad_scale, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,349 @@
+// BatchNorm over NHWC tensors viewed as [N rows][C channels] (nn.BatchNorm2d / BatchNorm1d of the
+// reference, scripts/model.py:41,44,212,235,361; eps 1e-5, momentum 0.1).  All kernels are HBM-bound
+// float4 streams; reductions are two-level (fp32 per block -> fp64 fixed-order finalize), so they are
+// deterministic and do not lose precision over the 6.1 M-element layer-1 reductions.
+//
+// Forward (train):  conv epilogue or bn_stats_partial -> per-block (sum, sumsq) -> bn_finalize ->
+//                   (mean, invstd, scale = gamma*invstd, shift = beta - mean*scale, running stats)
+//                   -> bn_apply [+ residual] [+ ReLU]  (or fused into the next conv's input staging)
+// Backward:         bn_bwd_reduce -> (sum dz, sum dz*xhat) -> bn_bwd_finalize -> dgamma, dbeta, coefficients
+//                   -> bn_bwd_apply: draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+#include "spk_common.h"
+
+enum { MASK_NONE = 0, MASK_ACT = 1, MASK_RAW = 2 };
+
+// ---- statistics of a plain [N][C] tensor ---------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                               long long N, int C, int rows_per_block) {
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x;
+    const int qpr = C >> 2;            // float4 quads per row
+    const int quad = tid % qpr, prow = tid / qpr, rstep = 256 / qpr;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + prow; r < r1; r += rstep) {
+        const f32x4 v = *(const f32x4*)(x + r * C + quad * 4);
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid][k] = s[k];
+        red[tid][4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (tid < qpr) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = 0.f;
+        for (int p = 0; p < rstep; ++p)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[p * qpr + tid][k];
+        float* dst = partial + ((size_t)blockIdx.x * C + tid * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k * 2 + 0] = a[k];
+            dst[k * 2 + 1] = a[4 + k];
+        }
+    }
+}
+
+static bool bn_c_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
+
+extern "C" int spk_bn_stats_blocks(long long N, int C) {
+    (void)C;
+    long long nb = (N + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int spk_bn_stats_partial(const float* x, float* partial, long long N, int C, void* stream) {
+    SPK_REQUIRE(x && partial, "spk_bn_stats_partial: null pointer");
+    SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_stats_partial: N=%lld C=%d (C must be a power of two in [4,1024])", N, C);
+    const int nb = spk_bn_stats_blocks(N, C);
+    const int rpb = (int)((N + nb - 1) / nb);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, partial, N, C, rpb);
+    SPK_LAUNCH_CHECK("spk_bn_stats_partial");
+    return 0;
+}
+
+// ---- finalize: partial [nblk][C][2] -> mean/invstd/scale/shift (+ running statistics) ---------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ nbt, float* __restrict__ mean_out,
+                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float momentum, float eps) {
+    __shared__ double red[8][32][2];
+    const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    double s = 0.0, ss = 0.0;
+    if (ch < C) {
+        for (int k = row; k < nblk; k += 8) {
+            const float* p = partial + ((size_t)k * C + ch) * 2;
+            s += (double)p[0];
+            ss += (double)p[1];
+        }
+    }
+    red[row][c][0] = s;
+    red[row][c][1] = ss;
+    __syncthreads();
+    if (row == 0 && ch < C) {
+        for (int k = 1; k < 8; ++k) {
+            s += red[k][c][0];
+            ss += red[k][c][1];
+        }
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[ch], b = beta[ch];
+        const float sc = g * invstd;
+        mean_out[ch] = (float)mean;
+        invstd_out[ch] = invstd;
+        scale[ch] = sc;
+        shift[ch] = b - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && tid == 0) *nbt += 1;
+}
+
+extern "C" int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                               float* invstd, float* scale, float* shift, float momentum, float eps, void* stream) {
+    SPK_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift, "spk_bn_finalize: null pointer");
+    SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_finalize: bad sizes");
+    SPK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "spk_bn_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(spk_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift,
+                       momentum, eps);
+    SPK_LAUNCH_CHECK("spk_bn_finalize");
+    return 0;
+}
+
+// ---- eval-mode coefficients from running statistics ------------------------------------------------
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float* scale, float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float* scale, float* shift, int C, float eps, void* stream) {
+    SPK_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "spk_bn_eval_coeffs: null pointer");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(spk_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, scale, shift, C, eps);
+    SPK_LAUNCH_CHECK("spk_bn_eval_coeffs");
+    return 0;
+}
+
+// ---- apply: out = [relu]( raw*scale + shift [+ res | + res*rscale + rshift] ) -----------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                       float* __restrict__ out, long long nquads, int C, int relu) {
+    const int cmask = C - 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i * 4) & cmask);
+        f32x4 v = *(const f32x4*)(raw + i * 4);
+        v = v * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+        if (res) {
+            f32x4 rv = *(const f32x4*)(res + i * 4);
+            if (rscale) rv = rv * *(const f32x4*)(rscale + c) + *(const f32x4*)(rshift + c);
+            v += rv;
+        }
+        if (relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+        }
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+
+static int stream_grid(long long nquads) {
+    long long nb = (nquads + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res,
+                            const float* res_scale, const float* res_shift, float* out, long long N, int C, int relu,
+                            void* stream) {
+    SPK_REQUIRE(raw && scale && shift && out, "spk_bn_apply: null pointer");
+    SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_apply: N=%lld C=%d", N, C);
+    SPK_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), "spk_bn_apply: residual affine must come in pairs");
+    SPK_REQUIRE(!res_scale || res, "spk_bn_apply: residual affine without residual");
+    const long long nquads = N * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res,
+                       res_scale, res_shift, out, nquads, C, relu);
+    SPK_LAUNCH_CHECK("spk_bn_apply");
+    return 0;
+}
+
+// ---- backward reduce: partial[blk][c] = (sum dz, sum dz*xhat), dz = dy * mask ---------------------------
+__device__ inline f32x4 bn_mask(f32x4 dy, int mode, const float* act, const float* raw_p, f32x4 rawv, f32x4 sc, f32x4 sh,
+                                long long off) {
+    if (mode == MASK_ACT) {
+        const f32x4 a = *(const f32x4*)(act + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dy[k] = a[k] > 0.f ? dy[k] : 0.f;
+    } else if (mode == MASK_RAW) {
+        const f32x4 z = rawv * sc + sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dy[k] = z[k] > 0.f ? dy[k] : 0.f;
+    }
+    (void)raw_p;
+    return dy;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ raw,
+                                                            const float* __restrict__ act, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ partial,
+                                                            long long N, int C, int rows_per_block, int mode) {
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x;
+    const int qpr = C >> 2;
+    const int quad = tid % qpr, prow = tid / qpr, rstep = 256 / qpr;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    const f32x4 mu = *(const f32x4*)(mean + quad * 4), is = *(const f32x4*)(invstd + quad * 4);
+    const f32x4 sc = *(const f32x4*)(scale + quad * 4), sh = *(const f32x4*)(shift + quad * 4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + prow; r < r1; r += rstep) {
+        const long long off = r * C + quad * 4;
+        const f32x4 rv = *(const f32x4*)(raw + off);
+        f32x4 d = *(const f32x4*)(dy + off);
+        d = bn_mask(d, mode, act, raw, rv, sc, sh, off);
+        const f32x4 xh = (rv - mu) * is;
+        s += d;
+        ss += d * xh;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid][k] = s[k];
+        red[tid][4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (tid < qpr) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = 0.f;
+        for (int p = 0; p < rstep; ++p)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[p * qpr + tid][k];
+        float* dst = partial + ((size_t)blockIdx.x * C + tid * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k * 2 + 0] = a[k];
+            dst[k * 2 + 1] = a[4 + k];
+        }
+    }
+}
+
+extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
+                                 const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
+                                 void* stream) {
+    SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && partial, "spk_bn_bwd_reduce: null pointer");
+    SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_reduce: N=%lld C=%d", N, C);
+    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spk_bn_bwd_reduce: mask_mode=%d", mask_mode);
+    SPK_REQUIRE(mask_mode != MASK_ACT || act, "spk_bn_bwd_reduce: MASK_ACT needs the activated tensor");
+    const int nb = spk_bn_stats_blocks(N, C);
+    const int rpb = (int)((N + nb - 1) / nb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean, invstd, scale,
+                       shift, partial, N, C, rpb, mask_mode);
+    SPK_LAUNCH_CHECK("spk_bn_bwd_reduce");
+    return 0;
+}
+
+// ---- backward finalize: dgamma, dbeta and the apply coefficients coef[3][C] = (gamma*invstd, dbeta/n, dgamma/n)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int accumulate) {
+    __shared__ double red[8][32][2];
+    const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    double s = 0.0, ss = 0.0;
+    if (ch < C) {
+        for (int k = row; k < nblk; k += 8) {
+            const float* p = partial + ((size_t)k * C + ch) * 2;
+            s += (double)p[0];
+            ss += (double)p[1];
+        }
+    }
+    red[row][c][0] = s;
+    red[row][c][1] = ss;
+    __syncthreads();
+    if (row == 0 && ch < C) {
+        for (int k = 1; k < 8; ++k) {
+            s += red[k][c][0];
+            ss += red[k][c][1];
+        }
+        dbeta[ch] = accumulate ? dbeta[ch] + (float)s : (float)s;
+        dgamma[ch] = accumulate ? dgamma[ch] + (float)ss : (float)ss;
+        coef[ch] = gamma[ch] * invstd[ch];
+        coef[C + ch] = (float)(s / count);
+        coef[2 * C + ch] = (float)(ss / count);
+    }
+}
+
+extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma,
+                                   const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate,
+                                   void* stream) {
+    SPK_REQUIRE(partial && gamma && invstd && dgamma && dbeta && coef, "spk_bn_bwd_finalize: null pointer");
+    SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_bwd_finalize: bad sizes");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(spk_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                       count, gamma, invstd, dgamma, dbeta, coef, accumulate);
+    SPK_LAUNCH_CHECK("spk_bn_bwd_finalize");
+    return 0;
+}
+
+// ---- backward apply: draw = k1*(dz - m1 - xhat*m2); optionally also stores dz (the residual-path gradient)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ raw,
+                                                           const float* __restrict__ act, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ coef,
+                                                           float* __restrict__ draw, float* __restrict__ dz_out,
+                                                           long long nquads, int C, int mode) {
+    const int cmask = C - 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i * 4) & cmask);
+        const long long off = i * 4;
+        const f32x4 rv = *(const f32x4*)(raw + off);
+        f32x4 d = *(const f32x4*)(dy + off);
+        d = bn_mask(d, mode, act, raw, rv, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), off);
+        const f32x4 xh = (rv - *(const f32x4*)(mean + c)) * *(const f32x4*)(invstd + c);
+        const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
+        const f32x4 o = k1 * (d - m1 - xh * m2);
+        if (dz_out) *(f32x4*)(dz_out + off) = d;
+        *(f32x4*)(draw + off) = o;
+    }
+}
+
+extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
+                                const float* scale, const float* shift, const float* coef, float* draw, float* dz_out,
+                                long long N, int C, int mask_mode, void* stream) {
+    SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && coef && draw, "spk_bn_bwd_apply: null pointer");
+    SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_apply: N=%lld C=%d", N, C);
+    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
+    SPK_REQUIRE(mask_mode != MASK_ACT || act, "spk_bn_bwd_apply: MASK_ACT needs the activated tensor");
+    const long long nquads = N * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
+                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode);
+    SPK_LAUNCH_CHECK("spk_bn_bwd_apply");
+    return 0;
+}

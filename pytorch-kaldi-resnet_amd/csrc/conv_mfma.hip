@@ -1,0 +1,307 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves: 3x3 / 1x1 forward at stride 1 / 2 (scripts/model.py:12-15,105-110,233-234
+// of the reference, i.e. nn.Conv2d(bias=False)), and the data gradient of each of them
+// (a stride-2 data gradient runs as four parity classes, each a dense conv with a tap subset).
+// The caller describes the conv as a tap table: for logical output pixel (oy,ox) and tap t the
+// input pixel is (oy*IS + dy[t], ox*IS + dx[t]); the logical output pixel is stored at
+// (oy*OS + ooy, ox*OS + oox) of the physical NHWC output.
+//
+// Data layout: activations NHWC fp32.  Weights are pre-packed (spk_pack_conv_weight) in MFMA
+// B-fragment order [tap][Cin/8][Cout/32][lane 0..63][4]: lane l holds, for cout = 32*nt + (l&31),
+// the four cin values 8*g + 4*(l>>5) + {0,1,2,3}.  A block stages the input halo tile of a
+// TH x TW pixel region for a 32-channel chunk into LDS once ([pixel][32+4 pad] floats) and all
+// taps read it with shifted pixel offsets; B fragments stream straight from L2 into registers
+// (1 KiB coalesced per wave-instruction, shared by the block's four waves through L1).
+// GEMM view: M = pixels (rows of the 32x32 tile), N = cout (lanes), K = (tap, cin).
+// K is consumed 8 at a time: one ds_read_b128 + one global_load_dwordx4 feed four MFMAs, the
+// two lane halves taking cin {0..3} and {4..7} of the group (any K order is a valid sum).
+#include "spk_common.h"
+
+#define CK 32
+#define LPS 36  // LDS floats per staged pixel: 32 + 4 pad -> conflict-free ds_read_b128
+
+struct ConvArgs {
+    const float* in;
+    const float* wpk;
+    float* out;
+    const float* in_scale;
+    const float* in_shift;
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_add;
+    float* stats;
+    int B, IH, IW, Cin;
+    int OH, OW;            // logical output grid
+    int OHf, OWf, Cout;    // physical output tensor
+    int IS, OS, ooy, oox;
+    int TH, TW, tiles_y, tiles_x;
+    int halo_h, halo_w, min_dy, min_dx;
+    int ntaps, ncg, nblocks, flags;
+    signed char tap_dy[12], tap_dx[12], tap_w[12];
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
+    // order (same pixel region, next cout group; then the neighbouring region) share an XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int n = a.nblocks, q = n >> 3, rr = n & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+    }
+    const int cg = bid % a.ncg;
+    const int ptile = bid / a.ncg;
+    int pt = ptile;
+    const int tx = pt % a.tiles_x;
+    pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int b = pt / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * a.IS + a.min_dy, ix0 = ox0 * a.IS + a.min_dx;
+    const int npix_tile = a.TH * a.TW;
+    const int n0 = cg * NT * 32;
+    const int flags = a.flags;
+
+    int lbase[MT], obase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int q = (wave * MT + i) * 32 + r;
+        bool v = q < npix_tile;
+        const int qq = v ? q : 0;
+        const int ly = qq / a.TW, lx = qq - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        v = v && oy < a.OH && ox < a.OW;
+        lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LPS + h * 4;
+        obase[i] = v ? ((b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox) * a.Cout + n0 : -1;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = a.Cin / CK;
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int cout32 = a.Cout >> 5;
+    const int quad = tid & 7;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();  // every wave is done reading the previous chunk's tile
+        {
+            const int c = ch * CK + quad * 4;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (flags & SPK_IN_AFFINE_RELU) {
+                sc = *(const f32x4*)(a.in_scale + c);
+                sh = *(const f32x4*)(a.in_shift + c);
+            }
+            int p = tid >> 3;
+            int hy = p / a.halo_w, hx = p - hy * a.halo_w;
+            for (; p < halo_pix; p += 32) {
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+                    v = *(const f32x4*)(a.in + (size_t)((b * a.IH + iy) * a.IW + ix) * a.Cin + c);
+                    if (flags & SPK_IN_AFFINE_RELU) {
+                        v = v * sc + sh;
+                        v[0] = fmaxf(v[0], 0.f);
+                        v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f);
+                        v[3] = fmaxf(v[3], 0.f);
+                    }
+                }
+                *(f32x4*)(lds + p * LPS + quad * 4) = v;
+                hx += 32;
+                while (hx >= a.halo_w) {
+                    hx -= a.halo_w;
+                    ++hy;
+                }
+            }
+        }
+        __syncthreads();
+
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int toff = ((a.tap_dy[t] - a.min_dy) * a.halo_w + (a.tap_dx[t] - a.min_dx)) * LPS;
+            const float* wp = a.wpk + ((size_t)(a.tap_w[t] * (a.Cin >> 3) + ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bf[NT], af[MT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + ((size_t)g * cout32 + j) * 256);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *(const f32x4*)(lds + lbase[i] + toff + g * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 tile is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float es[NT], eh[NT], ssum[NT], ssq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        es[j] = 1.f;
+        eh[j] = 0.f;
+        ssum[j] = 0.f;
+        ssq[j] = 0.f;
+        if (flags & SPK_EPI_AFFINE) {
+            es[j] = a.epi_scale[n0 + j * 32 + r];
+            eh[j] = a.epi_shift[n0 + j * 32 + r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int ob = __shfl(obase[i], row, 64);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v = acc[i][j][e];
+                if (ob >= 0) {
+                    const int addr = ob + j * 32 + r;
+                    if (flags & SPK_EPI_AFFINE) v = v * es[j] + eh[j];
+                    if (flags & SPK_EPI_ADD) v += a.epi_add[addr];
+                    if (flags & SPK_EPI_RELU) v = fmaxf(v, 0.f);
+                    a.out[addr] = v;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (flags & SPK_EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            ssum[j] += __shfl_xor(ssum[j], 32, 64);
+            ssq[j] += __shfl_xor(ssq[j], 32, 64);
+        }
+        __syncthreads();  // LDS tile no longer needed
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                lds[((wave * NT + j) * 32 + r) * 2 + 0] = ssum[j];
+                lds[((wave * NT + j) * 32 + r) * 2 + 1] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 32) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s0 += lds[((w * NT) * 32 + tid) * 2 + 0];
+                s1 += lds[((w * NT) * 32 + tid) * 2 + 1];
+            }
+            float* dst = a.stats + ((size_t)ptile * a.Cout + n0 + tid) * 2;
+            dst[0] = s0;
+            dst[1] = s1;
+        }
+    }
+}
+
+template <int MT, int NT>
+static int launch_conv(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_mfma");
+    return 0;
+}
+
+extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale,
+                             const float* in_shift, const float* epi_scale, const float* epi_shift,
+                             const float* epi_add, float* stats, int B, int IH, int IW, int Cin, int OH,
+                             int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
+                             const int* tap_dy, const int* tap_dx, const int* tap_w, int TH, int TW, int MT,
+                             int NT, int flags, void* stream) {
+    SPK_REQUIRE(in && wpk && out, "spk_conv_mfma: null pointer");
+    SPK_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "spk_conv_mfma: empty tensor");
+    SPK_REQUIRE(Cin % 32 == 0 && Cin > 0, "spk_conv_mfma: Cin=%d must be a multiple of 32", Cin);
+    SPK_REQUIRE(NT >= 1 && Cout % (32 * NT) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT (NT=%d)", Cout, NT);
+    SPK_REQUIRE(ntaps >= 1 && ntaps <= 9, "spk_conv_mfma: ntaps=%d out of range", ntaps);
+    SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT, "spk_conv_mfma: tile %dx%d exceeds 128*MT (MT=%d)", TH, TW, MT);
+    SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
+    SPK_REQUIRE((OH - 1) * OS + ooy < OHf && (OW - 1) * OS + oox < OWf, "spk_conv_mfma: logical grid exceeds the output tensor");
+    SPK_REQUIRE((long long)B * OHf * OWf * Cout < 2147483647LL && (long long)B * IH * IW * Cin < 2147483647LL * 4,
+                "spk_conv_mfma: tensor too large for 32-bit element offsets");
+    SPK_REQUIRE(!(flags & SPK_IN_AFFINE_RELU) || (in_scale && in_shift), "spk_conv_mfma: IN_AFFINE_RELU needs scale/shift");
+    SPK_REQUIRE(!(flags & SPK_EPI_AFFINE) || (epi_scale && epi_shift), "spk_conv_mfma: EPI_AFFINE needs scale/shift");
+    SPK_REQUIRE(!(flags & SPK_EPI_ADD) || epi_add, "spk_conv_mfma: EPI_ADD needs epi_add");
+    SPK_REQUIRE(!(flags & SPK_EPI_STATS) || stats, "spk_conv_mfma: EPI_STATS needs a stats buffer");
+    ConvArgs a;
+    a.in = in; a.wpk = wpk; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;
+    a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
+    a.IS = IS; a.OS = OS; a.ooy = ooy; a.oox = oox; a.TH = TH; a.TW = TW;
+    a.tiles_y = spk_ceil_div(OH, TH); a.tiles_x = spk_ceil_div(OW, TW);
+    int mindy = 127, mindx = 127, maxdy = -127, maxdx = -127;
+    for (int t = 0; t < ntaps; ++t) {
+        SPK_REQUIRE(tap_dy[t] >= -8 && tap_dy[t] <= 8 && tap_dx[t] >= -8 && tap_dx[t] <= 8 && tap_w[t] >= 0 && tap_w[t] < 9,
+                    "spk_conv_mfma: tap %d out of range", t);
+        a.tap_dy[t] = (signed char)tap_dy[t]; a.tap_dx[t] = (signed char)tap_dx[t]; a.tap_w[t] = (signed char)tap_w[t];
+        if (tap_dy[t] < mindy) mindy = tap_dy[t];
+        if (tap_dy[t] > maxdy) maxdy = tap_dy[t];
+        if (tap_dx[t] < mindx) mindx = tap_dx[t];
+        if (tap_dx[t] > maxdx) maxdx = tap_dx[t];
+    }
+    a.min_dy = mindy; a.min_dx = mindx;
+    a.halo_h = (TH - 1) * IS + (maxdy - mindy) + 1;
+    a.halo_w = (TW - 1) * IS + (maxdx - mindx) + 1;
+    a.ntaps = ntaps; a.ncg = Cout / (32 * NT);
+    a.nblocks = B * a.tiles_y * a.tiles_x * a.ncg;
+    a.flags = flags;
+    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * LPS * sizeof(float);
+    const size_t red_bytes = (size_t)4 * NT * 32 * 2 * sizeof(float);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(M, N) if (MT == M && NT == N) return launch_conv<M, N>(a, lds_bytes, st)
+    CASE(1, 1); CASE(2, 1); CASE(3, 1); CASE(4, 1);
+    CASE(1, 2); CASE(2, 2); CASE(3, 2); CASE(4, 2);
+    CASE(1, 4); CASE(2, 4);
+#undef CASE
+    spk_set_error("spk_conv_mfma: unsupported tile config MT=%d NT=%d", MT, NT);
+    return -1;
+}
+
+// ---- weight packing -------------------------------------------------------------------------
+// OIHW [Cout][Cin][KH][KW] -> [tap][K/8][N/32][64][4].  transpose == 0: K = cin, N = cout (forward);
+// transpose == 1: K = cout, N = cin (data gradient).  Tap index t = kh*KW + kw in both cases.
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
+                                        int KHW, int transpose, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+    int i = idx;
+    const int s = i & 3; i >>= 2;
+    const int lane = i & 63; i >>= 6;
+    const int nt = i % (N >> 5); i /= (N >> 5);
+    const int g = i % (K >> 3);
+    const int t = i / (K >> 3);
+    const int n = nt * 32 + (lane & 31);
+    const int k = g * 8 + (lane >> 5) * 4 + s;
+    const int co = transpose ? k : n, ci = transpose ? n : k;
+    wpk[idx] = w[((size_t)co * Cin + ci) * KHW + t];
+}
+
+extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose,
+                                    void* stream) {
+    SPK_REQUIRE(w && wpk, "spk_pack_conv_weight: null pointer");
+    SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight: channels (%d,%d) must be multiples of 32", Cout, Cin);
+    SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight: kernel %dx%d unsupported", KH, KW);
+    const int total = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wpk, Cout, Cin, KH * KW, transpose, total);
+    SPK_LAUNCH_CHECK("spk_pack_conv_weight");
+    return 0;
+}

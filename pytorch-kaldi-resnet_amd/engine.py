@@ -1,0 +1,341 @@
+"""Execution engine: sequences the libspkhip kernels for the forward, backward and inference passes of
+NeuralSpeakerModel.  Pure orchestration - every tensor op is a HIP kernel launch from ops.py.
+
+Data flow of one BasicBlock in training (reference scripts/model.py:48-64), NHWC fp32:
+    raw1 = conv1(x)            [stats in the conv epilogue]    -> bn1 finalize (mean/invstd/scale/shift)
+    raw2 = conv2(relu(bn1(raw1)))   bn1+relu fused into conv2's input staging, never materialised
+    out  = relu(bn2(raw2) + shortcut)                          one fused elementwise pass
+so each block costs 7 tensor passes over HBM instead of 11.  Saved for backward: x, raw1, raw2, out (+ the
+downsample's raw output).  Backward recomputes relu(bn1(raw1)) on the fly inside wgrad's input staging.
+"""
+import torch
+
+from . import ops
+from .hip import MASK_ACT, MASK_NONE, MASK_RAW
+
+
+class _Conv:
+    def __init__(self, holder):
+        self.h = holder
+        self.cin, self.cout, self.k, self.stride = holder.cin, holder.cout, holder.k, holder.stride
+        self.wpk = None
+        self.wpk_t = None
+
+    def repack(self, need_t):
+        w = self.h.weight.data
+        if self.cin == 1:
+            return
+        self.wpk = ops.pack_conv_weight(w, False, self.wpk)
+        if need_t:
+            self.wpk_t = ops.pack_conv_weight(w, True, self.wpk_t)
+
+
+class _BN:
+    def __init__(self, holder):
+        self.h = holder
+        self.c = holder.c
+        self.t4 = None      # train: [mean, invstd, scale, shift]
+        self.e2 = None      # eval:  [scale, shift]
+
+    def finalize(self, partial, count):
+        if self.t4 is None:
+            self.t4 = torch.empty(4, self.c, device=partial.device, dtype=torch.float32)
+        h = self.h
+        ops.bn_finalize(partial, count, h.weight.data, h.bias.data, h.running_mean, h.running_var, h.num_batches_tracked,
+                        self.t4)
+        return self.t4
+
+    def eval_coeffs(self):
+        h = self.h
+        if self.e2 is None:
+            self.e2 = torch.empty(2, self.c, device=h.weight.device, dtype=torch.float32)
+        ops.bn_eval_coeffs(h.weight.data, h.bias.data, h.running_mean, h.running_var, self.e2)
+        return self.e2
+
+
+class _Block:
+    def __init__(self, bp):
+        self.kind = bp.kind
+        self.convs = [_Conv(bp.conv1), _Conv(bp.conv2)] + ([_Conv(bp.conv3)] if bp.kind == "bottleneck" else [])
+        self.bns = [_BN(bp.bn1), _BN(bp.bn2)] + ([_BN(bp.bn3)] if bp.kind == "bottleneck" else [])
+        self.ds = None
+        if bp.downsample is not None:
+            self.ds = (_Conv(bp.downsample[0]), _BN(bp.downsample[1]))
+
+
+class _LogitsFn(torch.autograd.Function):
+    """Bridges torch autograd to the hand-written backward: one node for the whole network.  Parameter
+    gradients are written straight into the flat gradient arena (the .grad views); `anchor` only makes the
+    output require grad."""
+
+    @staticmethod
+    def forward(ctx, eng, x, y, anchor):
+        logits, saved = eng.forward_train(x, y)
+        ctx.eng = eng
+        ctx.saved = saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.eng.backward(ctx.saved, dlogits.contiguous())
+        ctx.saved = None
+        return None, None, None, None
+
+
+class Engine:
+    def __init__(self, model):
+        self.m = model
+        r = model.res
+        self.stem_conv = _Conv(r.conv1)
+        self.stem_bn = _BN(r.bn1)
+        self.blocks = []
+        for li in range(1, 5):
+            for bp in getattr(r, "layer%d" % li):
+                self.blocks.append(_Block(bp))
+        self.head_bn = _BN(model.bn1) if hasattr(model, "bn1") else None
+        self.pool_mode = 1 if model.pooling == "mean+std" else 0
+        self.dirty = True
+        self._packed_for_bwd = False
+
+    # ---- helpers ---------------------------------------------------------------------------------------
+    def _all_convs(self):
+        for b in self.blocks:
+            for c in b.convs:
+                yield c
+            if b.ds is not None:
+                yield b.ds[0]
+
+    def _repack(self, need_t):
+        if not self.dirty and (self._packed_for_bwd or not need_t):
+            return
+        for c in self._all_convs():
+            c.repack(need_t)
+        self.dirty = False
+        self._packed_for_bwd = need_t
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("pytorch_kaldi_resnet_amd runs on MI355X only: input must be a device tensor "
+                               "(there is no CPU fallback)")
+        if x.dim() != 3 or x.size(1) != self.m.feat_dim:
+            raise RuntimeError("expected input [B, %d, T], got %s" % (self.m.feat_dim, tuple(x.shape)))
+        if x.dtype != torch.float32:
+            raise RuntimeError("expected float32 input")
+        return x.contiguous()
+
+    # ---- inference trunk (eval-mode BN folded into conv epilogues) -----------------------------------------
+    def trunk_eval(self, x):
+        self._repack(False)
+        e = self.stem_bn.eval_coeffs()
+        a, _ = ops.stem_fwd(x, self.stem_conv.h.weight.data, epi_affine=(e[0], e[1]), relu=True)
+        for b in self.blocks:
+            evs = [bn.eval_coeffs() for bn in b.bns]
+            if b.ds is not None:
+                ed = b.ds[1].eval_coeffs()
+                res, _ = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, epi_affine=(ed[0], ed[1]))
+            else:
+                res = a
+            h = a
+            n = len(b.convs)
+            for i, (c, ev) in enumerate(zip(b.convs, evs)):
+                last = i == n - 1
+                h, _ = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, epi_affine=(ev[0], ev[1]),
+                                    epi_add=res if last else None, relu=True)
+            a = h
+        return a
+
+    def embed_eval(self, x):
+        feat = self.trunk_eval(x)
+        pooled = ops.stats_pool_fwd(feat, self.pool_mode)
+        return ops.linear_fwd(pooled, self.m.fc1.weight.data, self.m.fc1.bias.data)
+
+    def predict(self, x):
+        """scripts/model.py:402-409.  Uses BN batch statistics when the module is in train mode, exactly like
+        the reference would; decode.py always calls it under model.eval()."""
+        x = self._check_input(x)
+        with torch.no_grad():
+            if self.m.training:
+                emb, _ = self._embed_train(x, save=False)
+                return emb
+            return self.embed_eval(x)
+
+    # ---- heads ----------------------------------------------------------------------------------------------
+    def _head_fwd(self, emb, y, train, save):
+        m = self.m
+        sv = {}
+        h = emb
+        if m.loss in ("softmax", "AAM-v1"):
+            bn = self.head_bn
+            if train:
+                part = ops.bn_stats_partial(emb)
+                t4 = bn.finalize(part, emb.shape[0])
+                h = ops.bn_apply(emb, t4[2], t4[3], relu=True)
+            else:
+                e2 = bn.eval_coeffs()
+                h = ops.bn_apply(emb, e2[0], e2[1], relu=True)
+            sv["h"] = h
+        if m.loss == "softmax":
+            logits = ops.linear_fwd(h, m.last.weight.data, m.last.bias.data)
+        else:
+            if y is None:
+                raise RuntimeError("AAM heads need labels (scripts/model.py:483: label=None fails in the reference too)")
+            y = y.contiguous()
+            hn, hinv = ops.l2norm_fwd(h)
+            wn, winv = ops.l2norm_fwd(m.last.weight.data)
+            B, S, D = h.shape[0], wn.shape[0], wn.shape[1]
+            cosv = ops.gemm(hn, wn, B, S, D, D, 1, 1, D)
+            logits = ops.aam_margin_fwd(cosv, y, m.m, m.s)
+            if save:
+                sv.update(hn=hn, hinv=hinv, wn=wn, winv=winv, cosv=cosv, y=y)
+        return logits, sv
+
+    def _head_bwd(self, emb, sv, dlogits, acc):
+        m = self.m
+        if m.loss == "softmax":
+            dh = ops.linear_bwd(sv["h"], m.last.weight.data, dlogits, m.last.weight.grad, m.last.bias.grad, accumulate=acc)
+        else:
+            dcos = ops.aam_margin_bwd(sv["cosv"], sv["y"], dlogits, m.m, m.s)
+            B, S = dcos.shape
+            D = sv["wn"].shape[1]
+            dhn = ops.gemm(dcos, sv["wn"], B, D, S, S, 1, D, 1)
+            dwn = ops.gemm(dcos, sv["hn"], S, D, B, 1, S, D, 1)
+            dh = ops.l2norm_bwd(sv["hn"], sv["hinv"], dhn)
+            ops.l2norm_bwd(sv["wn"], sv["winv"], dwn, out=m.last.weight.grad, accumulate=acc)
+        if m.loss in ("softmax", "AAM-v1"):
+            bn = self.head_bn
+            dh = ops.bn_backward(dh, emb, sv["h"], bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
+                                 accumulate=acc)
+        return dh
+
+    # ---- training forward -----------------------------------------------------------------------------------
+    def _trunk_train(self, x, save):
+        saved = {"x": x, "blocks": []}
+        raw0, st = ops.stem_fwd(x, self.stem_conv.h.weight.data, stats=True)
+        B, F, T, _ = raw0.shape
+        t4 = self.stem_bn.finalize(st, B * F * T)
+        a = ops.bn_apply(raw0, t4[2], t4[3], relu=True)
+        saved["raw0"] = raw0
+        for b in self.blocks:
+            rec = {"x": a}
+            raws = []
+            h, aff = a, None
+            for c, bn in zip(b.convs, b.bns):
+                raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True)
+                t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2])
+                raws.append(raw)
+                h, aff = raw, (t4[2], t4[3])
+            if b.ds is not None:
+                rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True)
+                td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2])
+                out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True)
+                rec["rawd"] = rawd
+            else:
+                out = ops.bn_apply(h, aff[0], aff[1], res=a, relu=True)
+            rec["raws"] = raws
+            rec["out"] = out
+            if save:
+                saved["blocks"].append(rec)
+            a = out
+        return a, saved
+
+    def _embed_train(self, x, save):
+        self._repack(save)
+        feat, saved = self._trunk_train(x, save)
+        pooled = ops.stats_pool_fwd(feat, self.pool_mode)
+        emb = ops.linear_fwd(pooled, self.m.fc1.weight.data, self.m.fc1.bias.data)
+        saved["feat"], saved["pooled"], saved["emb"] = feat, pooled, emb
+        return emb, saved
+
+    def forward_train(self, x, y):
+        emb, saved = self._embed_train(x, True)
+        logits, sv = self._head_fwd(emb, y, True, True)
+        saved["head"] = sv
+        return logits, saved
+
+    def forward_logits(self, x, y=None):
+        x = self._check_input(x)
+        m = self.m
+        if m.training and torch.is_grad_enabled():
+            anchor = m.fc1.bias
+            return _LogitsFn.apply(self, x, y, anchor)
+        with torch.no_grad():
+            if m.training:
+                emb, _ = self._embed_train(x, save=False)
+                logits, _ = self._head_fwd(emb, y, True, False)
+            else:
+                emb = self.embed_eval(x)
+                logits, _ = self._head_fwd(emb, y, False, False)
+            return logits
+
+    # ---- backward ---------------------------------------------------------------------------------------------
+    def backward(self, saved, dlogits, on_stage_done=None):
+        """Hand-written backward of forward_train.  Parameter gradients go to the .grad arena views (overwritten
+        when the views are fresh, accumulated otherwise).  on_stage_done(name) is called after the last weight
+        gradient of each ResNet stage has been enqueued (hook for overlapping the gradient all-reduce)."""
+        m = self.m
+        acc = not m.attach_grads()
+        with torch.no_grad():
+            demb = self._head_bwd(saved["emb"], saved["head"], dlogits, acc)
+            dpooled = ops.linear_bwd(saved["pooled"], m.fc1.weight.data, demb, m.fc1.weight.grad, m.fc1.bias.grad,
+                                     accumulate=acc)
+            d = ops.stats_pool_bwd(saved["feat"], dpooled, self.pool_mode)
+            if on_stage_done:
+                on_stage_done("head")
+            nblk = len(self.blocks)
+            stage_of = []
+            for li in range(1, 5):
+                stage_of += [li] * len(getattr(m.res, "layer%d" % li))
+            for bi in range(nblk - 1, -1, -1):
+                d = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc)
+                saved["blocks"][bi] = None
+                if on_stage_done and (bi == 0 or stage_of[bi - 1] != stage_of[bi]):
+                    on_stage_done("layer%d" % stage_of[bi])
+            # stem: d is the gradient wrt relu(bn(raw0))
+            bn = self.stem_bn
+            draw0 = ops.bn_backward(d, saved["raw0"], None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad,
+                                    MASK_RAW, draw_out=d, accumulate=acc)
+            ops.stem_wgrad(saved["x"], draw0, self.stem_conv.h.weight.grad, accumulate=acc)
+            if on_stage_done:
+                on_stage_done("stem")
+
+    def _block_bwd(self, b, rec, dout, acc):
+        x, raws, out = rec["x"], rec["raws"], rec["out"]
+        n = len(b.convs)
+        # last BN (+ residual + relu): dz is written over dout and is the shortcut gradient
+        bn = b.bns[n - 1]
+        draw = ops.bn_backward(dout, raws[n - 1], out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
+                               dz_out=dout, accumulate=acc)
+        dz = dout
+        for i in range(n - 1, 0, -1):
+            c, pbn = b.convs[i], b.bns[i - 1]
+            # conv i consumed relu(bn_{i-1}(raw_{i-1})) through its fused input transform
+            ops.conv_wgrad(raws[i - 1], draw, c.h.weight.grad, c.k, c.stride, in_affine=(pbn.t4[2], pbn.t4[3]),
+                           accumulate=acc)
+            da = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (raws[i - 1].shape[1], raws[i - 1].shape[2]))
+            draw = ops.bn_backward(da, raws[i - 1], None, pbn.t4, pbn.h.weight.data, pbn.h.weight.grad, pbn.h.bias.grad,
+                                   MASK_RAW, draw_out=da, accumulate=acc)
+        c = b.convs[0]
+        ops.conv_wgrad(x, draw, c.h.weight.grad, c.k, c.stride, accumulate=acc)
+        if b.ds is None:
+            dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]), add=dz)
+        else:
+            dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]))
+            cd, bnd = b.ds
+            drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
+                                    MASK_NONE, draw_out=dz, accumulate=acc)
+            ops.conv_wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
+            ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True)
+        return dx
+
+    # ---- fused training step (forward + CE + backward, no autograd graph) --------------------------------------
+    def loss_and_grad(self, x, y, on_stage_done=None):
+        """One iteration of scripts/train_resnet.py:316-327 without the autograd shell: returns
+        (loss [1] device tensor, logits, rank [B] int32 for accuracy).  Gradients land in the .grad arena."""
+        x = self._check_input(x)
+        y = y.contiguous()
+        with torch.no_grad():
+            logits, saved = self.forward_train(x, y)
+            loss_row, dl, rank = ops.softmax_ce(logits, y, grad_scale=1.0 / logits.shape[0])
+            loss = ops.mean(loss_row)
+        self.backward(saved, dl, on_stage_done)
+        return loss, logits, rank

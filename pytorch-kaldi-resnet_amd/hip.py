@@ -1,0 +1,100 @@
+"""ctypes binding of libspkhip.so (include/spkhip.h).  Fails loudly when the library is missing:
+there is no CPU or eager-PyTorch fallback anywhere in this package."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspkhip.so")
+
+IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS = 1, 2, 4, 8, 16
+MASK_NONE, MASK_ACT, MASK_RAW = 0, 1, 2
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_longlong
+_F = ctypes.c_float
+_D = ctypes.c_double
+_IP = ctypes.POINTER(ctypes.c_int)
+
+_SIGS = {
+    "spk_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "spk_conv_mfma": [_P] * 9 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 5 + [_P],
+    "spk_conv_wgrad": [_P] * 6 + [_I] * 15 + [_P],
+    "spk_stem_fwd_blocks": [_I, _I, _I],
+    "spk_stem_conv_fwd": [_P] * 6 + [_I] * 4 + [_P],
+    "spk_stem_wgrad_blocks": [_I, _I, _I],
+    "spk_stem_conv_wgrad": [_P] * 4 + [_I] * 4 + [_P],
+    "spk_bn_stats_blocks": [_L, _I],
+    "spk_bn_stats_partial": [_P, _P, _L, _I, _P],
+    "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P],
+    "spk_bn_eval_coeffs": [_P] * 6 + [_I, _F, _P],
+    "spk_bn_apply": [_P] * 7 + [_L, _I, _I, _P],
+    "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P],
+    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P],
+    "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P],
+    "spk_stats_pool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "spk_gemm_f32": [_P] * 4 + [_I] * 3 + [_L] * 5 + [_F, _I, _P],
+    "spk_colsum": [_P, _P, _I, _I, _I, _P],
+    "spk_l2norm_fwd": [_P, _P, _P, _I, _I, _F, _P],
+    "spk_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "spk_aam_margin_fwd": [_P, _P, _P, _I, _I, _F, _F, _P],
+    "spk_aam_margin_bwd": [_P, _P, _P, _P, _I, _I, _F, _F, _P],
+    "spk_softmax_ce": [_P] * 5 + [_I, _I, _F, _P],
+    "spk_mean": [_P, _P, _I, _P],
+    "spk_relu_bwd": [_P, _P, _P, _L, _P],
+    "spk_sgd_step": [_P, _P, _P, _L, _F, _F, _F, _F, _I, _P],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libspkhip.so (built by build.py / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libspkhip.so is missing at %s: run `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        l.spk_last_error.restype = ctypes.c_char_p
+        l.spk_version.restype = ctypes.c_int
+        l.spk_conv_wgrad_workspace.restype = ctypes.c_size_t
+        l.spk_conv_wgrad_workspace.argtypes = [_I, _I, _I, _I]
+        for name, sig in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = sig
+            fn.restype = ctypes.c_int
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return ["spk_version", "spk_last_error", "spk_conv_wgrad_workspace"] + list(_SIGS)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Requires a contiguous fp32/int64/int32 CUDA(HIP) tensor."""
+    if t is None:
+        return None
+    assert t.is_cuda, "libspkhip takes device tensors only"
+    assert t.is_contiguous(), "libspkhip takes contiguous tensors only"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = lib().spk_last_error().decode()
+        raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, msg))
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,321 @@
+"""Thin Python wrappers over the libspkhip exports: shape checks, output allocation (torch caching
+allocator owns every device buffer), tile selection, tap tables.  No arithmetic happens here."""
+import ctypes
+
+import torch
+
+from . import hip, tiling
+from .hip import (EPI_ADD, EPI_AFFINE, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, MASK_ACT, MASK_NONE, MASK_RAW,
+                  call, ptr, stream)
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _iarr(v):
+    return (ctypes.c_int * len(v))(*v)
+
+
+def conv_out_hw(h, w, ksize, stride):
+    pad = 1 if ksize == 3 else 0
+    return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+
+
+def pack_conv_weight(w, transpose=False, out=None):
+    """OIHW nn.Conv2d weight -> MFMA fragment order (see csrc/conv_mfma.hip)."""
+    Cout, Cin, KH, KW = w.shape
+    if out is None:
+        out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    call("spk_pack_conv_weight", ptr(w), ptr(out), Cout, Cin, KH, KW, 1 if transpose else 0, stream())
+    return out
+
+
+def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats):
+    B, IH, IW, Cin = x.shape
+    OHf, OWf = out.shape[1], out.shape[2]
+    dys = [t[0] for t in taps]
+    dxs = [t[1] for t in taps]
+    tws = [t[2] for t in taps]
+    TH, TW, MT, NT = tiling.conv_tile(OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
+    flags = 0
+    if in_affine is not None:
+        flags |= IN_AFFINE_RELU
+    if epi_affine is not None:
+        flags |= EPI_AFFINE
+    if epi_add is not None:
+        flags |= EPI_ADD
+        assert epi_add.shape == out.shape
+    if relu:
+        flags |= EPI_RELU
+    stats = None
+    if want_stats:
+        flags |= EPI_STATS
+        ntile = B * (-(-OH // TH)) * (-(-OW // TW))
+        stats = torch.empty(ntile, Cout, 2, device=x.device, dtype=torch.float32)
+    call("spk_conv_mfma", ptr(x), ptr(wpk), ptr(out),
+         ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
+         ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
+         ptr(epi_add), ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
+         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream())
+    return stats
+
+
+def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_add=None, relu=False, stats=False,
+             out=None):
+    """Forward conv on NHWC x with packed weights. Returns (out, stats_partial or None)."""
+    B, IH, IW, Cin = x.shape
+    OH, OW = conv_out_hw(IH, IW, ksize, stride)
+    if out is None:
+        out = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
+    if ksize == 3:
+        taps = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    else:
+        taps = [(0, 0, 0)]
+    st = _conv_launch(x, wpk, out, Cout, taps, stride, 1, 0, 0, OH, OW, in_affine, epi_affine, epi_add, relu, stats)
+    return out, st
+
+
+def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False):
+    """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
+    `add` (same shape as dx) is summed in the epilogue; accumulate=True adds onto the existing `out`."""
+    B, OH, OW, Cout = dy.shape
+    IH, IW = in_hw
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, IH, IW, Cin, device=dy.device, dtype=torch.float32)
+    if accumulate:
+        assert add is None
+        add = out
+    if stride == 1:
+        if ksize == 3:
+            taps = [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+        else:
+            taps = [(0, 0, 0)]
+        _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False)
+        return out
+    assert stride == 2
+    if ksize == 1:
+        # only even input pixels receive gradient from a strided 1x1 conv
+        if not accumulate:
+            if add is not None:
+                out.copy_(add)
+            else:
+                out.zero_()
+        _conv_launch(dy, wpk_t, out, Cin, [(0, 0, 0)], 1, 2, 0, 0, (IH + 1) // 2, (IW + 1) // 2, None, None, out, False,
+                     False)
+        return out
+    for cy in range(2):
+        for cx in range(2):
+            LH, LW = (IH - cy + 1) // 2, (IW - cx + 1) // 2
+            if LH <= 0 or LW <= 0:
+                continue
+            taps = []
+            for kh in range(3):
+                if (cy + 1 - kh) % 2:
+                    continue
+                for kw in range(3):
+                    if (cx + 1 - kw) % 2:
+                        continue
+                    taps.append(((cy + 1 - kh) // 2, (cx + 1 - kw) // 2, kh * 3 + kw))
+            _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False)
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = str(device)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() * 4 < nbytes:
+        w = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _ws_cache[key] = w
+    return w
+
+
+def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
+    """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy."""
+    B, IH, IW, Cin = x.shape
+    _, OH, OW, Cout = dy.shape
+    TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride)
+    nreg = B * (-(-OH // TH)) * (-(-OW // TW))
+    nsplit = tiling.wgrad_nsplit(nreg, Cin, Cout, WN)
+    nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
+    ws = _workspace(nbytes, x.device)
+    flags = IN_AFFINE_RELU if in_affine is not None else 0
+    call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
+         ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
+         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, stream())
+    return dw
+
+
+def stem_fwd(x, w, epi_affine=None, relu=False, stats=False):
+    """x [B][F][T] -> [B][F][T][32] (+ stats partial [nblk][32][2])."""
+    B, F, T = x.shape
+    out = torch.empty(B, F, T, 32, device=x.device, dtype=torch.float32)
+    flags = (EPI_AFFINE if epi_affine is not None else 0) | (EPI_RELU if relu else 0) | (EPI_STATS if stats else 0)
+    st = None
+    if stats:
+        st = torch.empty(hip.lib().spk_stem_fwd_blocks(B, F, T), 32, 2, device=x.device, dtype=torch.float32)
+    call("spk_stem_conv_fwd", ptr(x), ptr(w), ptr(out), ptr(st),
+         ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None, B, F, T, flags, stream())
+    return out, st
+
+
+def stem_wgrad(x, draw, dw, accumulate=False):
+    B, F, T = x.shape
+    nblk = hip.lib().spk_stem_wgrad_blocks(B, F, T)
+    ws = _workspace(nblk * 288 * 4, x.device)
+    call("spk_stem_conv_wgrad", ptr(x), ptr(draw), ptr(dw), ptr(ws), B, F, T, 1 if accumulate else 0, stream())
+    return dw
+
+
+def bn_stats_partial(x2d):
+    N, C = x2d.shape
+    nblk = hip.lib().spk_bn_stats_blocks(N, C)
+    part = torch.empty(nblk, C, 2, device=x2d.device, dtype=torch.float32)
+    call("spk_bn_stats_partial", ptr(x2d), ptr(part), N, C, stream())
+    return part
+
+
+def bn_finalize(partial, count, gamma, beta, running_mean, running_var, nbt, out4):
+    """out4: tensor [4][C] = (mean, invstd, scale, shift)."""
+    C = gamma.numel()
+    call("spk_bn_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+         ptr(running_var), ptr(nbt), ptr(out4[0]), ptr(out4[1]), ptr(out4[2]), ptr(out4[3]), BN_MOMENTUM, BN_EPS, stream())
+
+
+def bn_eval_coeffs(gamma, beta, rm, rv, out2):
+    C = gamma.numel()
+    call("spk_bn_eval_coeffs", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(out2[0]), ptr(out2[1]), C, BN_EPS, stream())
+
+
+def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None):
+    C = raw.shape[-1]
+    N = raw.numel() // C
+    if out is None:
+        out = torch.empty_like(raw)
+    call("spk_bn_apply", ptr(raw), ptr(scale), ptr(shift), ptr(res),
+         ptr(res_affine[0]) if res_affine else None, ptr(res_affine[1]) if res_affine else None, ptr(out), N, C,
+         1 if relu else 0, stream())
+    return out
+
+
+def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False):
+    """Full BN backward (reduce -> finalize -> apply). bn4 = [mean, invstd, scale, shift] rows.
+    Returns draw (gradient wrt the raw conv output)."""
+    C = raw.shape[-1]
+    N = raw.numel() // C
+    nblk = hip.lib().spk_bn_stats_blocks(N, C)
+    part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
+    coef = torch.empty(3, C, device=raw.device, dtype=torch.float32)
+    call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
+         N, C, mask_mode, stream())
+    call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
+         1 if accumulate else 0, stream())
+    if draw_out is None:
+        draw_out = torch.empty_like(raw)
+    call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
+         ptr(draw_out), ptr(dz_out), N, C, mask_mode, stream())
+    return draw_out
+
+
+def stats_pool_fwd(x, mode):
+    B, H, W, C = x.shape
+    out = torch.empty(B, C * H * (2 if mode else 1), device=x.device, dtype=torch.float32)
+    call("spk_stats_pool_fwd", ptr(x), ptr(out), B, H, W, C, mode, stream())
+    return out
+
+
+def stats_pool_bwd(x, gout, mode):
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    call("spk_stats_pool_bwd", ptr(x), ptr(gout), ptr(dx), B, H, W, C, mode, stream())
+    return dx
+
+
+def gemm(A, Bm, M, N, K, sam, sak, sbk, sbn, bias=None, out=None, alpha=1.0, accumulate=False):
+    """out[M][N] = alpha * sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn] (+bias[n]) (+out)."""
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    call("spk_gemm_f32", ptr(A), ptr(Bm), ptr(out), ptr(bias), M, N, K, sam, sak, sbk, sbn, out.stride(0), float(alpha),
+         1 if accumulate else 0, stream())
+    return out
+
+
+def linear_fwd(x, w, bias=None):
+    """x [M][K] @ w[N][K]^T + bias."""
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm(x, w, M, N, K, K, 1, 1, K, bias=bias)
+
+
+def linear_bwd(x, w, dy, dw, db=None, need_dx=True, accumulate=False):
+    """Gradients of linear_fwd: dx [M][K] = dy @ w; dw [N][K] = dy^T @ x; db = colsum(dy)."""
+    M, K = x.shape
+    N = w.shape[0]
+    dx = None
+    if need_dx:
+        dx = gemm(dy, w, M, K, N, N, 1, K, 1)
+    gemm(dy, x, N, K, M, 1, N, K, 1, out=dw, accumulate=accumulate)
+    if db is not None:
+        call("spk_colsum", ptr(dy), ptr(db), M, N, 1 if accumulate else 0, stream())
+    return dx
+
+
+def l2norm_fwd(x):
+    R, D = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(R, device=x.device, dtype=torch.float32)
+    call("spk_l2norm_fwd", ptr(x), ptr(y), ptr(inv), R, D, 1e-12, stream())
+    return y, inv
+
+
+def l2norm_bwd(y, inv, dy, out=None, accumulate=False):
+    R, D = y.shape
+    if out is None:
+        out = torch.empty_like(y)
+    call("spk_l2norm_bwd", ptr(y), ptr(inv), ptr(dy), ptr(out), R, D, 1e-12, 1 if accumulate else 0, stream())
+    return out
+
+
+def aam_margin_fwd(cosv, label, m, s):
+    B, S = cosv.shape
+    logits = torch.empty_like(cosv)
+    call("spk_aam_margin_fwd", ptr(cosv), ptr(label), ptr(logits), B, S, float(m), float(s), stream())
+    return logits
+
+
+def aam_margin_bwd(cosv, label, dlogits, m, s):
+    B, S = cosv.shape
+    dcos = torch.empty_like(cosv)
+    call("spk_aam_margin_bwd", ptr(cosv), ptr(label), ptr(dlogits), ptr(dcos), B, S, float(m), float(s), stream())
+    return dcos
+
+
+def softmax_ce(logits, label, grad_scale=None, want_rank=True):
+    """-> (loss_row [B], dlogits or None, rank [B] int32 or None)."""
+    B, S = logits.shape
+    loss_row = torch.empty(B, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if grad_scale is not None else None
+    rank = torch.empty(B, device=logits.device, dtype=torch.int32) if want_rank else None
+    call("spk_softmax_ce", ptr(logits), ptr(label), ptr(loss_row), ptr(dl), ptr(rank), B, S,
+         float(grad_scale if grad_scale is not None else 0.0), stream())
+    return loss_row, dl, rank
+
+
+def mean(v):
+    out = torch.empty(1, device=v.device, dtype=torch.float32)
+    call("spk_mean", ptr(v), ptr(out), v.numel(), stream())
+    return out
+
+
+def relu_bwd(y, dy):
+    dx = torch.empty_like(dy)
+    call("spk_relu_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), stream())
+    return dx
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first):
+    call("spk_sgd_step", ptr(p), ptr(g), ptr(buf), p.numel(), float(lr), float(momentum), float(weight_decay),
+         float(grad_scale), 1 if first else 0, stream())

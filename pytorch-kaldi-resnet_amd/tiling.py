@@ -1,0 +1,74 @@
+"""Host-side tile selection for the MFMA convolution kernels (pure Python, cached per shape).
+
+A block of spk_conv_mfma covers a TH x TW region of logical output pixels (<= 128*MT, MT m-tiles of 32
+pixels per wave, 4 waves) and NT*32 output channels; its input halo tile lives in LDS at 144 B per
+pixel.  The chooser minimises a cycle model: MFMA time of the padded region plus staging time of the
+halo, with penalties for configurations that cut occupancy (registers at MT*NT >= 8, LDS > 52 KiB).
+"""
+from functools import lru_cache
+
+LDS_PIX_BYTES = 144
+LDS_SOFT = 52 * 1024      # 3 blocks / CU
+LDS_HARD = 80 * 1024      # 2 blocks / CU
+
+
+@lru_cache(maxsize=None)
+def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
+    """-> (TH, TW, MT, NT).  kspan = max tap offset - min tap offset + 1 per axis."""
+    NT = 1 if Cout % 64 else 2
+    best = None
+    for MT in (2, 3, 4, 1):
+        cap = 128 * MT
+        for TH in range(1, min(OH, cap) + 1):
+            tw_max = min(OW, cap // TH)
+            if tw_max < 1:
+                break
+            for TW in range(1, tw_max + 1):
+                # only maximal widths for a given tile count are interesting
+                tx = -(-OW // TW)
+                if TW > 1 and -(-OW // (TW - 1)) == tx and TW != tw_max:
+                    pass
+                ty = -(-OH // TH)
+                halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
+                lds = halo * LDS_PIX_BYTES
+                if lds > LDS_HARD:
+                    continue
+                cost = ty * tx * (cap * ntaps * NT * 4.5 + halo * 8.0)
+                if MT * NT >= 8:
+                    cost *= 1.25
+                if lds > LDS_SOFT:
+                    cost *= 1.08
+                if MT == 1:
+                    cost *= 1.05
+                key = (cost, -TH * TW)
+                if best is None or key < best[0]:
+                    best = (key, (TH, TW, MT, NT))
+    assert best is not None, "no conv tile for %dx%d" % (OH, OW)
+    return best[1]
+
+
+@lru_cache(maxsize=None)
+def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, nregions_per_image_hint=0):
+    """-> (TH, TW, WN).  TW even; LDS = X halo (128 B/pixel) + dY tile (WN*128 B/pixel) <= 72 KiB."""
+    WN = 1 if Cout == 32 else 2
+    best = None
+    OWe = OW + (OW & 1)
+    for TH in range(1, OH + 1):
+        for TW in range(2, OWe + 1, 2):
+            halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
+            lds = halo * 128 + TH * TW * WN * 128
+            if lds > 72 * 1024:
+                continue
+            ty, tx = -(-OH // TH), -(-OW // TW)
+            # MFMA work ~ padded pixels; staging ~ halo + tile; small tiles pay more barriers
+            cost = ty * tx * (TH * TW * 9.0 * (ksize * ksize) / 9.0 * 32 + halo * 8.0 + TH * TW * WN * 8.0 + 600.0)
+            key = (cost, -TH * TW)
+            if best is None or key < best[0]:
+                best = (key, (TH, TW, WN))
+    assert best is not None
+    return best[1]
+
+
+def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=768):
+    per = (Cin // 32) * (Cout // (32 * WN))
+    return max(1, min(nregions, target_blocks // per))

@@ -1,0 +1,280 @@
+"""Per-kernel parity on a real MI355X: every libspkhip export against the CPU oracle (oracle/spk_oracle.py)
+or, for bare ops the oracle only calls through torch (conv2d / batch_norm), against the same torch-CPU
+fp32 op.  All inputs are seeded; sizes finish in seconds on CPU.  Tolerances are stated per assertion
+(fp32 MFMA = exact fp32 FMA chain; only the summation order differs from ATen's)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spk_oracle as O  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import pytorch_kaldi_resnet_amd  # noqa: F401
+    from pytorch_kaldi_resnet_amd import ops as _ops
+    return _ops
+
+
+def rnd(seed, *shape, scale=1.0, shift=0.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(((W.hash_uniform(seed, 1, n) * 2 - 1) * scale + shift).astype(np.float32).reshape(shape))
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(x):   # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(x):   # NHWC cuda -> NCHW cpu
+    return x.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, ksize, stride
+    (2, 32, 32, 9, 13, 3, 1),
+    (1, 32, 32, 80, 300, 3, 1),
+    (2, 64, 128, 10, 38, 3, 1),
+    (2, 32, 64, 20, 75, 3, 2),
+    (2, 128, 256, 20, 75, 3, 2),
+    (3, 32, 64, 21, 14, 1, 2),
+    (2, 64, 64, 7, 9, 1, 1),
+    (2, 256, 256, 10, 38, 3, 1),
+    (1, 256, 256, 5, 3, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    B, Cin, Cout, H, Wd, k, s = case
+    pad = 1 if k == 3 else 0
+    x = rnd(1, B, Cin, H, Wd)
+    w = rnd(2, Cout, Cin, k, k, scale=0.2)
+    ref = F.conv2d(x, w, None, s, pad)
+    xg, wg = nhwc(x), w.cuda()
+    wpk = ops.pack_conv_weight(wg)
+    out, _ = ops.conv_fwd(xg, wpk, Cout, k, s)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, ref.shape[2], ref.shape[3], Cout)
+    e = relerr(nchw(out), ref)
+    assert e < 2e-5, "fwd %g" % e
+    # stats epilogue (train-mode BN partial sums)
+    out2, st = ops.conv_fwd(xg, wpk, Cout, k, s, stats=True)
+    tot = st.double().sum(0).cpu()
+    np.testing.assert_allclose(tot[:, 0].numpy(), ref.double().sum((0, 2, 3)).numpy(), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().sum((0, 2, 3)).max()))
+    np.testing.assert_allclose(tot[:, 1].numpy(), (ref.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-4)
+    # fused input BN+ReLU and inference epilogue (affine + residual + relu)
+    isc, ish = rnd(3, Cin, scale=0.5, shift=1.0), rnd(4, Cin, scale=0.3)
+    esc, esh = rnd(5, Cout, scale=0.5, shift=1.0), rnd(6, Cout, scale=0.3)
+    res = rnd(7, *ref.shape)
+    xa = F.relu(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+    ref2 = F.relu(F.conv2d(xa, w, None, s, pad) * esc.view(1, -1, 1, 1) + esh.view(1, -1, 1, 1) + res)
+    out3, _ = ops.conv_fwd(xg, wpk, Cout, k, s, in_affine=(isc.cuda(), ish.cuda()), epi_affine=(esc.cuda(), esh.cuda()),
+                           epi_add=nhwc(res), relu=True)
+    e = relerr(nchw(out3), ref2)
+    assert e < 2e-5, "fused fwd %g" % e
+    # data gradient
+    dy = rnd(8, *ref.shape)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    gx, gw = torch.autograd.grad((F.conv2d(xr, wr, None, s, pad) * dy).sum(), [xr, wr])
+    wpk_t = ops.pack_conv_weight(wg, transpose=True)
+    dx = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd))
+    e = relerr(nchw(dx), gx)
+    assert e < 2e-5, "dgrad %g" % e
+    addt = rnd(9, B, Cin, H, Wd)
+    dx2 = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt))
+    e = relerr(nchw(dx2), gx + addt)
+    assert e < 2e-5, "dgrad+add %g" % e
+    dx3 = nhwc(addt).clone()
+    ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), out=dx3, accumulate=True)
+    e = relerr(nchw(dx3), gx + addt)
+    assert e < 2e-5, "dgrad accumulate %g" % e
+    # weight gradient (plain and with the fused input transform)
+    dw = torch.empty(Cout, Cin, k, k, device="cuda")
+    ops.conv_wgrad(xg, nhwc(dy), dw, k, s)
+    e = relerr(dw.cpu(), gw)
+    assert e < 3e-5, "wgrad %g" % e
+    xr2 = x.clone()
+    gw2, = torch.autograd.grad((F.conv2d(F.relu(xr2 * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1)), wr, None, s, pad) * dy).sum(), [wr])
+    ops.conv_wgrad(xg, nhwc(dy), dw, k, s, in_affine=(isc.cuda(), ish.cuda()))
+    e = relerr(dw.cpu(), gw2)
+    assert e < 3e-5, "wgrad fused %g" % e
+    ops.conv_wgrad(xg, nhwc(dy), dw, k, s, in_affine=(isc.cuda(), ish.cuda()), accumulate=True)
+    e = relerr(dw.cpu(), 2 * gw2)
+    assert e < 3e-5, "wgrad accumulate %g" % e
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 13), (3, 80, 200), (1, 40, 37)])
+def test_stem(ops, shape):
+    B, Fd, T = shape
+    x = rnd(11, B, Fd, T)
+    w = rnd(12, 32, 1, 3, 3, scale=0.5)
+    ref = F.conv2d(x.view(B, 1, Fd, T), w, None, 1, 1)
+    out, st = ops.stem_fwd(x.cuda(), w.cuda(), stats=True)
+    assert relerr(nchw(out), ref) < 1e-6
+    tot = st.double().sum(0).cpu()
+    np.testing.assert_allclose(tot[:, 0].numpy(), ref.double().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(tot[:, 1].numpy(), (ref.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-5)
+    esc, esh = rnd(13, 32, scale=0.5, shift=1.0), rnd(14, 32, scale=0.3)
+    out2, _ = ops.stem_fwd(x.cuda(), w.cuda(), epi_affine=(esc.cuda(), esh.cuda()), relu=True)
+    assert relerr(nchw(out2), F.relu(ref * esc.view(1, -1, 1, 1) + esh.view(1, -1, 1, 1))) < 1e-6
+    dy = rnd(15, *ref.shape)
+    wr = w.clone().requires_grad_(True)
+    gw, = torch.autograd.grad((F.conv2d(x.view(B, 1, Fd, T), wr, None, 1, 1) * dy).sum(), [wr])
+    dw = torch.empty(32, 1, 3, 3, device="cuda")
+    ops.stem_wgrad(x.cuda(), nhwc(dy), dw)
+    assert relerr(dw.cpu(), gw) < 1e-5
+
+
+@pytest.mark.parametrize("C,N", [(32, 1000), (64, 777), (256, 64), (128, 5000)])
+def test_batchnorm_train_fwd_bwd(ops, C, N):
+    x = rnd(21, N, C, scale=2.0, shift=0.5)
+    gamma, beta = rnd(22, C, scale=0.3, shift=1.0), rnd(23, C, scale=0.2)
+    rm, rv = rnd(24, C, scale=0.1), rnd(25, C, scale=0.2, shift=1.0)
+    res = rnd(26, N, C)
+    dy = rnd(27, N, C)
+    # oracle: F.batch_norm train mode on [N,C] + residual + relu, autograd for the backward
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.relu(F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5) + res)
+    gx, gg, gb = torch.autograd.grad((y * dy).sum(), [xr, gr, br])
+    xg = x.cuda()
+    part = ops.bn_stats_partial(xg)
+    bn4 = torch.empty(4, C, device="cuda")
+    rmg, rvg = rm.cuda(), rv.cuda()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    ops.bn_finalize(part, N, gamma.cuda(), beta.cuda(), rmg, rvg, nbt, bn4)
+    out = ops.bn_apply(xg, bn4[2], bn4[3], res=res.cuda(), relu=True)
+    assert relerr(out.cpu(), y.detach()) < 2e-6
+    assert relerr(rmg.cpu(), rm_ref) < 1e-6 and relerr(rvg.cpu(), rv_ref) < 1e-6
+    assert int(nbt) == 1
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dz = torch.empty(N, C, device="cuda")
+    draw = ops.bn_backward(dy.cuda(), xg, out, bn4, gamma.cuda(), dgam, dbet, ops.MASK_ACT, dz_out=dz)
+    assert relerr(draw.cpu(), gx) < 2e-5
+    assert relerr(dgam.cpu(), gg) < 2e-5 and relerr(dbet.cpu(), gb) < 2e-5
+    assert relerr(dz.cpu(), dy * (y.detach() > 0)) == 0.0
+    # MASK_RAW: relu directly after BN, mask recomputed from raw
+    y2 = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    gx2, = torch.autograd.grad((y2 * dy).sum(), [xr])
+    draw2 = ops.bn_backward(dy.cuda(), xg, None, bn4, gamma.cuda(), dgam, dbet, ops.MASK_RAW)
+    assert relerr(draw2.cpu(), gx2) < 2e-5
+    # MASK_NONE: no relu (downsample BN)
+    y3 = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    gx3, = torch.autograd.grad((y3 * dy).sum(), [xr])
+    draw3 = ops.bn_backward(dy.cuda(), xg, None, bn4, gamma.cuda(), dgam, dbet, ops.MASK_NONE)
+    assert relerr(draw3.cpu(), gx3) < 2e-5
+    # eval coefficients
+    ev = torch.empty(2, C, device="cuda")
+    ops.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rmg, rvg, ev)
+    y4 = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5)
+    out4 = ops.bn_apply(xg, ev[0], ev[1], relu=False)
+    assert relerr(out4.cpu(), y4) < 2e-6
+
+
+def test_stats_pool_golden_and_random(ops, gold_dir):
+    g = np.load(os.path.join(gold_dir, "kernels.npz"))
+    x = torch.from_numpy(g["pool_x"])            # NCHW [2,4,3,13]
+    for mode, name in [(0, "mean"), (1, "mean+std")]:
+        y = ops.stats_pool_fwd(nhwc(x), mode)
+        ref = g["pool_%s_y" % name].reshape(2, -1)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-6, atol=1e-7)
+        gy = torch.from_numpy(g["pool_%s_gy" % name].reshape(2, -1)).cuda()
+        dx = ops.stats_pool_bwd(nhwc(x), gy, mode)
+        np.testing.assert_allclose(nchw(dx).numpy(), g["pool_%s_gx" % name], rtol=1e-5, atol=1e-7)
+    xr = rnd(31, 3, 256, 10, 38, scale=0.5, shift=0.6)
+    yo = O.stats_pool(xr, "mean+std").flatten(1)
+    y = ops.stats_pool_fwd(nhwc(xr), 1)
+    assert relerr(y.cpu(), yo) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 5120), (6, 11, 256), (256, 1211, 256), (37, 70, 129)])
+def test_gemm_and_linear(ops, M, N, K):
+    x, w, b = rnd(41, M, K), rnd(42, N, K, scale=0.1), rnd(43, N)
+    ref = F.linear(x, w, b)
+    out = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+    assert relerr(out.cpu(), ref) < 1e-5
+    dy = rnd(44, M, N)
+    dw, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    dx = ops.linear_bwd(x.cuda(), w.cuda(), dy.cuda(), dw, db)
+    assert relerr(dx.cpu(), dy @ w) < 1e-5
+    assert relerr(dw.cpu(), dy.t() @ x) < 1e-5
+    assert relerr(db.cpu(), dy.sum(0)) < 1e-5
+
+
+def test_aam_head_golden(ops, gold_dir):
+    g = np.load(os.path.join(gold_dir, "kernels.npz"))
+    e, w, lab = torch.from_numpy(g["aam_e"]).cuda(), torch.from_numpy(g["aam_w"]).cuda(), torch.from_numpy(g["aam_lab"]).cuda()
+    B, D = e.shape
+    S = w.shape[0]
+    en, einv = ops.l2norm_fwd(e)
+    wn, winv = ops.l2norm_fwd(w)
+    cosv = ops.gemm(en, wn, B, S, D, D, 1, 1, D)
+    logits = ops.aam_margin_fwd(cosv, lab, 0.2, 30.0)
+    # row 2 is engineered with cos ~ 1 on its label: sine = sqrt(1 - cos^2) amplifies a 1-ulp difference in
+    # cos by ~cos/sine ~ 2.5e3, so that single logit is only comparable to ~1e-4 relative
+    lg_np, ref_lg = logits.cpu().numpy(), g["aam_logits"].copy()
+    assert abs(lg_np[2, 5] - ref_lg[2, 5]) < 2e-4 * abs(ref_lg[2, 5])
+    lg_np[2, 5] = ref_lg[2, 5]
+    np.testing.assert_allclose(lg_np, ref_lg, rtol=1e-5, atol=2e-5)
+    loss_row, dl, rank = ops.softmax_ce(logits, lab, grad_scale=1.0 / B)
+    assert abs(float(ops.mean(loss_row)) - float(g["aam_loss"])) < 1e-4
+    dcos = ops.aam_margin_bwd(cosv, lab, dl, 0.2, 30.0)
+    den = ops.gemm(dcos, wn, B, D, S, S, 1, D, 1)
+    dwn = ops.gemm(dcos, en, S, D, B, 1, S, D, 1)
+    de = ops.l2norm_bwd(en, einv, den)
+    dw = ops.l2norm_bwd(wn, winv, dwn)
+    # row 2 has cos ~ 1 on its label (sine ~ 0): the reference gradient is huge there, compare relative
+    assert relerr(de.cpu(), torch.from_numpy(g["aam_ge"])) < 1e-3
+    assert relerr(dw.cpu(), torch.from_numpy(g["aam_gw"])) < 1e-3
+    ok = [0, 1, 3, 4, 5]
+    np.testing.assert_allclose(de.cpu().numpy()[ok], g["aam_ge"][ok], rtol=1e-3, atol=1e-6)
+    # rank vs the oracle's top-k
+    lg = torch.from_numpy(g["aam_logits"])
+    acc1, acc5 = O.accuracy(lg, torch.from_numpy(g["aam_lab"]), (1, 5))
+    r = rank.cpu()
+    assert abs(float((r < 1).float().mean() * 100) - float(acc1)) < 1e-4
+    assert abs(float((r < 5).float().mean() * 100) - float(acc5)) < 1e-4
+
+
+def test_softmax_ce_large(ops):
+    B, S = 64, 5994
+    lg = rnd(51, B, S, scale=12.0)
+    y = torch.from_numpy((W.hash_uniform(52, 1, B) * S).astype(np.int64))
+    lr = lg.clone().requires_grad_(True)
+    loss = O.cross_entropy(lr, y)
+    g, = torch.autograd.grad(loss, [lr])
+    loss_row, dl, rank = ops.softmax_ce(lg.cuda(), y.cuda(), grad_scale=1.0 / B)
+    assert abs(float(ops.mean(loss_row)) - float(loss)) < 1e-5 * abs(float(loss))
+    assert relerr(dl.cpu(), g) < 1e-5
+
+
+def test_sgd_matches_oracle(ops):
+    n = 10007
+    p0, g1, g2 = rnd(61, n), rnd(62, n), rnd(63, n)
+    st = {"p": p0.clone()}
+    bufs = {}
+    O.sgd_step(st, {"p": g1}, bufs, 0.1, 0.9, 5e-4)
+    O.sgd_step(st, {"p": g2}, bufs, 0.05, 0.9, 5e-4)
+    n_pad = (n + 3) // 4 * 4
+    p = torch.zeros(n_pad, device="cuda")[:n]
+    p.copy_(p0)
+    buf = torch.zeros(n, device="cuda")
+    ops.sgd_step(p, g1.cuda(), buf, 0.1, 0.9, 5e-4, 1.0, True)
+    ops.sgd_step(p, g2.cuda(), buf, 0.05, 0.9, 5e-4, 1.0, False)
+    assert relerr(p.cpu(), st["p"]) < 1e-6
+    assert relerr(buf.cpu(), bufs["p"]) < 1e-6
