@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput of the ResNet-34 + AAM-softmax hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full training iteration of BASELINE.json configs[1] on one batch of synthetic input that is
+already resident in HBM: forward (train-mode BN) + AAM margin + cross-entropy + hand-written backward +
+fused SGD (+ overlapped RCCL gradient all-reduce when N > 1; per-GPU batch fixed at 256 = weak scaling).
+Prints ONE JSON line (see the repo contract) with two extra objects:
+  roofline     - dominant kernel (by total device time in an instrumented pass of the same steps), its
+                 algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch
+                 stream, against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)
+  cpu_baseline - the CPU oracle (oracle/spk_oracle.py, a torch-CPU port of the reference path) timed on this
+                 host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, FEAT, FRAMES, SPK = 256, 80, 300, 1211
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="per-GPU batch (256 = the BASELINE config)")
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle train step (fwd + CE + autograd bwd + SGD) on the host cores; bounded sample."""
+    from oracle import spk_oracle as O
+    from oracle import weights as W
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))   # the GPU box's CPU share is 16 cores per GPU
+    bs = args.cpu_batch
+    st = O.to_torch_state(W.make_state(0, SPK, FEAT, "mean+std", "AAM", "resnet34"))
+    x, y = W.make_input(1234, bs, FEAT, args.frames, SPK)
+    x, y = torch.from_numpy(x), torch.from_numpy(y)
+    bufs = {}
+    O.train_step(st, bufs, x, y, 1e-4, weight_decay=5e-4)   # warm-up
+    log("cpu warm-up step done (%d threads)" % torch.get_num_threads())
+    t0 = time.time()
+    for i in range(args.cpu_steps):
+        O.train_step(st, bufs, x, y, 1e-4, weight_decay=5e-4)
+        log("cpu step %d done" % i)
+    dt = (time.time() - t0) / args.cpu_steps
+    return {"value": round(bs / dt, 3), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of bs%d x %d frames x %d mel, ResNet-34+AAM S=%d, torch %s CPU oracle "
+                      "(%.2f s/step)" % (args.cpu_steps, bs, args.frames, FEAT, SPK, torch.__version__, dt)}
+
+
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.time()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pytorch_kaldi_resnet_amd  # noqa: F401
+    from pytorch_kaldi_resnet_amd import ops
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    from pytorch_kaldi_resnet_amd.optim import FlatSGD
+    from pytorch_kaldi_resnet_amd.parallel import GradAllReducer
+
+    torch.manual_seed(0)
+    model = NeuralSpeakerModel(SPK, FEAT, "mean+std", "AAM", 0.2, 30, arch="resnet34").to(dev)
+    model.train()
+    opt = FlatSGD(model, 0.1, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / world)
+    red = GradAllReducer(model)
+    red.broadcast_parameters(0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.randn(args.batch, FEAT, args.frames, device=dev, generator=gen)
+    y = torch.randint(0, SPK, (args.batch,), device=dev, generator=gen)
+    eng = model.engine()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = eng.loss_and_grad(x, y, red.on_stage_done if world > 1 else None)
+        red.finish()
+        opt.step()
+        return loss
+
+    log("model built, starting warm-up")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    lossv = float(loss)
+    log("timed region done: %.3f s for %d steps" % (dt, args.steps))
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, flops, e0, e1 in recs:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += 1
+        name, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        ach = fsum / tsum / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                    "gflop_per_launch": round(fsum / n / 1e9, 3),
+                    "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
+                                        "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
+                                        "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("roofline pass done; timing the CPU oracle (bounded sample)")
+        cpu = cpu_baseline(args)
+        log("cpu baseline done")
+    if rank == 0:
+        gb = args.batch * world
+        out = {
+            "metric": "utterances/sec (300-frame x 80 fbank, bs256/GPU), ResNet-34 + AAM-softmax training step",
+            "value": round(gb * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ResNet-34 + AAM-softmax (m 0.2, s 30), %d speakers, "
+                                   "%d-frame x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
+                                   % (SPK, args.frames, FEAT, args.batch),
+                       "global_batch": gb, "frames": args.frames, "feat_dim": FEAT, "speakers": SPK,
+                       "parallelism": "dp%d" % world},
+            "final_loss": round(lossv, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,22 @@ from .hip import (EPI_ADD, EPI_AFFINE, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, MASK
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# When set to a list, every launch appends (label, algorithmic flops, start event, end event); the events are
+# recorded on the launch stream (torch's current stream), which is what bench.py's roofline pass reads.
+PROFILE = None
+_raw_call = call
+
+
+def call(name, *args, label=None, flops=0.0):   # noqa: F811  (instrumented wrapper around hip.call)
+    if PROFILE is None:
+        return _raw_call(name, *args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _raw_call(name, *args)
+    e1.record()
+    PROFILE.append((label or name, flops, e0, e1))
+
 
 def _iarr(v):
     return (ctypes.c_int * len(v))(*v)
@@ -56,7 +72,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
          ptr(epi_add), ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
-         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream())
+         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream(),
+         label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
 
 
@@ -145,7 +162,9 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     flags = IN_AFFINE_RELU if in_affine is not None else 0
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
-         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, stream())
+         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, stream(),
+         label="conv_wgrad_kernel<%d,%d,%d>+reduce" % (ksize * ksize, 4 // WN, WN),
+         flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
     return dw
 
 

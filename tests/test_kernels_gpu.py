@@ -225,12 +225,8 @@ def test_aam_head_golden(ops, gold_dir):
     wn, winv = ops.l2norm_fwd(w)
     cosv = ops.gemm(en, wn, B, S, D, D, 1, 1, D)
     logits = ops.aam_margin_fwd(cosv, lab, 0.2, 30.0)
-    # row 2 is engineered with cos ~ 1 on its label: sine = sqrt(1 - cos^2) amplifies a 1-ulp difference in
-    # cos by ~cos/sine ~ 2.5e3, so that single logit is only comparable to ~1e-4 relative
-    lg_np, ref_lg = logits.cpu().numpy(), g["aam_logits"].copy()
-    assert abs(lg_np[2, 5] - ref_lg[2, 5]) < 2e-4 * abs(ref_lg[2, 5])
-    lg_np[2, 5] = ref_lg[2, 5]
-    np.testing.assert_allclose(lg_np, ref_lg, rtol=1e-5, atol=2e-5)
+    # row 2 is engineered with cos ~ 0.999 on its label (sine small): that logit is conditioned ~cos/sine worse
+    np.testing.assert_allclose(logits.cpu().numpy(), g["aam_logits"], rtol=2e-5, atol=5e-5)
     loss_row, dl, rank = ops.softmax_ce(logits, lab, grad_scale=1.0 / B)
     assert abs(float(ops.mean(loss_row)) - float(g["aam_loss"])) < 1e-4
     dcos = ops.aam_margin_bwd(cosv, lab, dl, 0.2, 30.0)
@@ -238,11 +234,8 @@ def test_aam_head_golden(ops, gold_dir):
     dwn = ops.gemm(dcos, en, S, D, B, 1, S, D, 1)
     de = ops.l2norm_bwd(en, einv, den)
     dw = ops.l2norm_bwd(wn, winv, dwn)
-    # row 2 has cos ~ 1 on its label (sine ~ 0): the reference gradient is huge there, compare relative
-    assert relerr(de.cpu(), torch.from_numpy(g["aam_ge"])) < 1e-3
-    assert relerr(dw.cpu(), torch.from_numpy(g["aam_gw"])) < 1e-3
-    ok = [0, 1, 3, 4, 5]
-    np.testing.assert_allclose(de.cpu().numpy()[ok], g["aam_ge"][ok], rtol=1e-3, atol=1e-6)
+    assert relerr(de.cpu(), torch.from_numpy(g["aam_ge"])) < 1e-4
+    assert relerr(dw.cpu(), torch.from_numpy(g["aam_gw"])) < 1e-4
     # rank vs the oracle's top-k
     lg = torch.from_numpy(g["aam_logits"])
     acc1, acc5 = O.accuracy(lg, torch.from_numpy(g["aam_lab"]), (1, 5))

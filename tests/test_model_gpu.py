@@ -1,0 +1,200 @@
+"""End-to-end parity of the HIP model against the reference-generated golden fixtures and the CPU oracle.
+
+What is compared, and why these tolerances:
+  * eval-mode embeddings / logits and train-mode logits / loss (forward only): well conditioned; the BASELINE
+    bar is cosine >= 1 - 1e-4, we assert 1e-6 on cosine and 2e-5 scale-relative on values.
+  * gradients: the trunk gradient of this network is ill-conditioned in fp32 - the oracle's OWN fp32 gradient
+    differs from its fp64 gradient by 5e-4 .. 3e-2 norm-relative depending on the batch (cancellation in the
+    BatchNorm backward; see DESIGN.md "gradient conditioning"), and a forward difference of 1e-5 (which is what
+    two correct fp32 implementations with different summation orders show after 30 layers) flips the ReLU mask of
+    the few activations with |z| < 1e-5, each flip moving one channel's bias gradient by a whole element.
+    Measured on MI355X: HIP-vs-fp64 1.2e-2 where oracle-fp32-vs-fp64 is 5.5e-4 (r34_softmax_mean_f40), 3.0e-2
+    vs 2.7e-2 (r101).  Budget asserted: 3x the fp32 oracle's own error + 2e-2 norm-relative on the whole
+    gradient, 5e-4 on the well-conditioned head matrices, 2e-2 on every parameter's gradient norm vs the
+    reference's recorded norms.
+  * loss curve over 5 SGD steps (lr 2e-5): |delta| <= 5e-3 (0.06 %) for the same reason.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spk_oracle as O  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+CASES = ["c1_r34_aam", "r34_aam_t203", "r34_aam_t300", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"]
+
+
+@pytest.fixture(scope="module")
+def P():
+    assert torch.cuda.is_available()
+    import pytorch_kaldi_resnet_amd as pkg
+    from pytorch_kaldi_resnet_amd import model, optim  # noqa: F401
+    return pkg
+
+
+def build(P, meta):
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    m = NeuralSpeakerModel(meta["spk_num"], meta["feat_dim"], meta["pooling"], meta["loss"], 0.2, 30, arch=meta["arch"])
+    npst = W.make_state(meta["seed"], meta["spk_num"], meta["feat_dim"], meta["pooling"], meta["loss"], meta["arch"])
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in npst.items()}
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), npst
+
+
+def cos_dist(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float((1 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))).max())
+
+
+def srel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_parity(P, gold_dir, name):
+    meta = json.load(open(os.path.join(gold_dir, name + ".json")))
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    m, _ = build(P, meta)
+    # state_dict naming / shapes are the reference's
+    keys = json.load(open(os.path.join(gold_dir, "state_keys_%s_%s.json" % (meta["arch"], meta["loss"])))) \
+        if os.path.exists(os.path.join(gold_dir, "state_keys_%s_%s.json" % (meta["arch"], meta["loss"]))) else None
+    if keys:
+        sd = m.state_dict()
+        assert list(sd.keys()) == [k for k, _ in keys]
+    x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.eval()
+    with torch.no_grad():
+        emb = m.predict(xg).cpu().numpy()
+        lg = m(xg, yg).cpu().numpy()
+    assert cos_dist(emb, g["emb_eval"]) < 1e-6          # BASELINE bar: 1e-4
+    assert srel(emb, g["emb_eval"]) < 2e-5
+    assert srel(lg, g["logits_eval"]) < 5e-5
+    m.train()
+    logits = m(xg, yg)
+    loss = torch.nn.functional.cross_entropy(logits, yg)
+    # train-mode BN over a batch of 2-4 utterances amplifies rounding differences more than eval mode
+    assert srel(logits.detach().cpu().numpy(), g["logits_train"]) < 2e-4
+    assert abs(float(loss) - float(g["loss_train"])) < 1e-4
+    # BN running statistics after exactly one training forward
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("rm:"):
+            np.testing.assert_allclose(sd[key[3:] + ".running_mean"].cpu().numpy(), g[key], rtol=1e-4, atol=1e-5)
+        if key.startswith("rv:"):
+            np.testing.assert_allclose(sd[key[3:] + ".running_var"].cpu().numpy(), g[key], rtol=1e-4, atol=1e-5)
+        if key.startswith("nbt:"):
+            assert int(sd[key[4:] + ".num_batches_tracked"]) == int(g[key])
+
+
+@pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"])
+def test_backward_parity(P, gold_dir, name):
+    meta = json.load(open(os.path.join(gold_dir, name + ".json")))
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    m, npst = build(P, meta)
+    x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.train()
+    logits = m(xg, yg)
+    loss = torch.nn.functional.cross_entropy(logits, yg)
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    assert names == meta["param_names"]
+    hip = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+    # oracle in fp32 and fp64 on the same inputs
+    kw = dict(pooling=meta["pooling"], loss=meta["loss"], arch=meta["arch"])
+
+    def oracle_grads(dtype):
+        st = O.to_torch_state(npst)
+        st = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
+        keys = O.trainable_keys(st)
+        for k in keys:
+            st[k].requires_grad_(True)
+        lo = O.forward(st, torch.from_numpy(x).to(dtype), torch.from_numpy(y), train=True, **kw)
+        lv = O.cross_entropy(lo, torch.from_numpy(y))
+        gs = torch.autograd.grad(lv, [st[k] for k in keys])
+        return {k: v.double() for k, v in zip(keys, gs)}
+
+    g32, g64 = oracle_grads(torch.float32), oracle_grads(torch.float64)
+
+    def flat(d):
+        return torch.cat([d[n].reshape(-1) for n in names])
+
+    f64 = flat(g64)
+    e_oracle = float((flat(g32) - f64).norm() / f64.norm())
+    e_hip = float((flat(hip) - f64).norm() / f64.norm())
+    print("grad error vs fp64: oracle-fp32 %.3e  hip %.3e" % (e_oracle, e_hip))
+    assert e_hip <= 3.0 * e_oracle + 2e-2
+    # head parameters are well conditioned
+    for n in names:
+        if n.startswith("fc1.weight") or n == "last.weight":
+            e = float((hip[n] - g64[n]).norm() / g64[n].norm())
+            assert e < 5e-4, (n, e)
+    # golden norms recorded from the reference itself
+    for i, n in enumerate(names):
+        ref = float(g["grad_norm"][i])
+        assert abs(float(hip[n].norm()) - ref) <= 2e-2 * ref + 1e-5, n
+
+
+def test_fused_step_equals_autograd_path(P, gold_dir):
+    meta = json.load(open(os.path.join(gold_dir, "c1_r34_aam.json")))
+    m, _ = build(P, meta)
+    x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.train()
+    logits = m(xg, yg)
+    loss = torch.nn.functional.cross_entropy(logits, yg)
+    loss.backward()
+    g1 = m.flat_grads().clone()
+    l1 = float(loss)
+    m2, _ = build(P, meta)
+    m2.train()
+    loss2, logits2, rank = m2.engine().loss_and_grad(xg, yg)
+    assert abs(float(loss2) - l1) < 1e-5
+    g2 = m2.flat_grads()
+    assert float((g1 - g2).norm() / g1.norm()) < 1e-5
+    acc1 = O.accuracy(logits2.cpu(), torch.from_numpy(y), (1,))[0]
+    assert abs(float((rank.cpu() < 1).float().mean() * 100) - float(acc1)) < 1e-4
+    # gradient accumulation semantics: a second backward without zero_grad adds onto the arena
+    g2c = g2.clone()
+    m2.engine().loss_and_grad(xg, yg)
+    assert float((m2.flat_grads() - 2 * g2c).norm() / g2c.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40"])
+def test_sgd_loss_curve(P, gold_dir, name):
+    from pytorch_kaldi_resnet_amd.optim import FlatSGD
+    meta = json.load(open(os.path.join(gold_dir, name + ".json")))
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    m, _ = build(P, meta)
+    opt = FlatSGD(m, meta["lr"], momentum=0.9, weight_decay=meta["wd"])
+    m.train()
+    losses = []
+    for s in range(meta["steps"]):
+        xs, ys = W.make_input(meta["seed"] + 1 + s, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+        xs, ys = torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()
+        out = m(xs, ys)
+        loss = torch.nn.functional.cross_entropy(out, ys)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("loss curve", losses, list(g["loss_curve"]))
+    np.testing.assert_allclose(losses, g["loss_curve"], rtol=0, atol=5e-3)
+    x, _ = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    m.eval()
+    with torch.no_grad():
+        e2 = m.predict(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert cos_dist(e2, g["emb_after"]) < 1e-4
+
+
+def test_cpu_input_is_refused(P):
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    m = NeuralSpeakerModel(5, 80, "mean+std", "AAM").cuda()
+    with pytest.raises(RuntimeError):
+        m.predict(torch.zeros(1, 80, 100))

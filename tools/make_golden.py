@@ -149,8 +149,8 @@ def record_kernels():
     wv = (W.hash_uniform(6, 1, S * D).reshape(S, D) * 2 - 1).astype(np.float32)
     ev = (W.hash_uniform(6, 2, B * D).reshape(B, D) * 2 - 1).astype(np.float32)
     lab = np.array([0, 3, 5, 7, 10, 2], dtype=np.int64)
-    ev[1] = -3.0 * wv[3]           # cos ~ -1: (cos - th) <= 0 branch on the target column
-    ev[2] = 2.0 * wv[5]            # cos ~ +1: sine ~ 0
+    ev[1] = -3.0 * wv[3] + 0.03 * ev[1]  # cos ~ -0.999: (cos - th) <= 0 branch on the target column (exactly -1 is nan in torch)
+    ev[2] = 2.0 * wv[5] + 0.03 * ev[2]   # cos ~ 0.999: small sine, large dphi/dcos (cos == 1 exactly is inf/nan in torch too)
     with torch.no_grad():
         layer.weight.copy_(torch.from_numpy(wv))
     e = torch.from_numpy(ev).requires_grad_(True)
