@@ -100,7 +100,9 @@ def main():
     from pytorch_kaldi_resnet_amd.parallel import GradAllReducer
 
     torch.manual_seed(0)
-    model = NeuralSpeakerModel(SPK, FEAT, "mean+std", "AAM", 0.2, 30, arch="resnet34").to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the model announces itself like the reference does; keep stdout = 1 JSON line
+        model = NeuralSpeakerModel(SPK, FEAT, "mean+std", "AAM", 0.2, 30, arch="resnet34").to(dev)
     model.train()
     opt = FlatSGD(model, 0.1, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / world)
     red = GradAllReducer(model)

@@ -77,9 +77,12 @@ int spk_bn_stats_blocks(long long N, int C);
 int spk_bn_stats_partial(const float* x, float* partial /*[blocks][C][2]*/, long long N, int C, void* stream);
 /* partial -> batch mean / invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated with
  * momentum and unbiased variance, *num_batches_tracked += 1 (pass NULLs to skip the running update) */
+/* ws: fp64 workspace of spk_bn_finalize_workspace(nblk, C) bytes (0 => may be NULL); used to fold many partial
+ * rows in parallel before the fixed-order final sum */
+size_t spk_bn_finalize_workspace(int nblk, int C);
 int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* invstd,
-                    float* scale, float* shift, float momentum, float eps, void* stream);
+                    float* scale, float* shift, float momentum, float eps, double* ws, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int C, float eps, void* stream);
@@ -91,7 +94,7 @@ int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
                       void* stream);
 int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* invstd,
-                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, void* stream);
+                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws, void* stream);
 int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,
                      int C, int mask_mode, void* stream);

@@ -70,7 +70,50 @@ extern "C" int spk_bn_stats_partial(const float* x, float* partial, long long N,
 }
 
 // ---- finalize: partial [nblk][C][2] -> mean/invstd/scale/shift (+ running statistics) ---------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+// Layer-1 convolutions emit ~25 k partial rows; a first stage folds them to <= 64 fp64 rows in parallel,
+// the second stage (one block per 32 channels) finishes in a fixed order.
+#define BN_STAGE_ROWS 64
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ partial, double* __restrict__ ws,
+                                                               int nblk, int C) {
+    __shared__ double red[8][32][2];
+    const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
+    const int ch = blockIdx.x * 32 + c;
+    const int per = (nblk + BN_STAGE_ROWS - 1) / BN_STAGE_ROWS;
+    const int k0 = blockIdx.y * per;
+    int k1 = k0 + per;
+    if (k1 > nblk) k1 = nblk;
+    double s = 0.0, ss = 0.0;
+    if (ch < C) {
+        for (int k = k0 + row; k < k1; k += 8) {
+            const float* p = partial + ((size_t)k * C + ch) * 2;
+            s += (double)p[0];
+            ss += (double)p[1];
+        }
+    }
+    red[row][c][0] = s;
+    red[row][c][1] = ss;
+    __syncthreads();
+    if (row == 0 && ch < C) {
+        for (int k = 1; k < 8; ++k) {
+            s += red[k][c][0];
+            ss += red[k][c][1];
+        }
+        ws[((size_t)blockIdx.y * C + ch) * 2 + 0] = s;
+        ws[((size_t)blockIdx.y * C + ch) * 2 + 1] = ss;
+    }
+}
+
+template <typename T>
+__device__ inline void bn_sum_rows(const T* __restrict__ partial, int nrows, int C, int ch, int row, double& s, double& ss) {
+    for (int k = row; k < nrows; k += 8) {
+        const T* p = partial + ((size_t)k * C + ch) * 2;
+        s += (double)p[0];
+        ss += (double)p[1];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ partial, int nblk, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ nbt, float* __restrict__ mean_out,
@@ -80,13 +123,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s = 0.0, ss = 0.0;
-    if (ch < C) {
-        for (int k = row; k < nblk; k += 8) {
-            const float* p = partial + ((size_t)k * C + ch) * 2;
-            s += (double)p[0];
-            ss += (double)p[1];
-        }
-    }
+    if (ch < C) bn_sum_rows<T>(partial, nblk, C, ch, row, s, ss);
     red[row][c][0] = s;
     red[row][c][1] = ss;
     __syncthreads();
@@ -114,15 +151,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (nbt && blockIdx.x == 0 && tid == 0) *nbt += 1;
 }
 
+extern "C" size_t spk_bn_finalize_workspace(int nblk, int C) {
+    return nblk > 4 * BN_STAGE_ROWS ? (size_t)BN_STAGE_ROWS * C * 2 * sizeof(double) : 0;
+}
+
 extern "C" int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
-                               float* invstd, float* scale, float* shift, float momentum, float eps, void* stream) {
+                               float* invstd, float* scale, float* shift, float momentum, float eps, double* ws,
+                               void* stream) {
     SPK_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift, "spk_bn_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_finalize: bad sizes");
     SPK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "spk_bn_finalize: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(spk_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
-                       count, gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift,
-                       momentum, eps);
+    hipStream_t st = (hipStream_t)stream;
+    if (spk_bn_finalize_workspace(nblk, C)) {
+        SPK_REQUIRE(ws, "spk_bn_finalize: %d partial rows need the fp64 workspace", nblk);
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
+        SPK_LAUNCH_CHECK("spk_bn_finalize(fold)");
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
+                           gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
+                           beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps);
+    }
     SPK_LAUNCH_CHECK("spk_bn_finalize");
     return 0;
 }
@@ -270,7 +320,8 @@ extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float*
 }
 
 // ---- backward finalize: dgamma, dbeta and the apply coefficients coef[3][C] = (gamma*invstd, dbeta/n, dgamma/n)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restrict__ partial, int nblk, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef, int accumulate) {
@@ -278,13 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
     double s = 0.0, ss = 0.0;
-    if (ch < C) {
-        for (int k = row; k < nblk; k += 8) {
-            const float* p = partial + ((size_t)k * C + ch) * 2;
-            s += (double)p[0];
-            ss += (double)p[1];
-        }
-    }
+    if (ch < C) bn_sum_rows<T>(partial, nblk, C, ch, row, s, ss);
     red[row][c][0] = s;
     red[row][c][1] = ss;
     __syncthreads();
@@ -303,11 +348,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate,
-                                   void* stream) {
+                                   double* ws, void* stream) {
     SPK_REQUIRE(partial && gamma && invstd && dgamma && dbeta && coef, "spk_bn_bwd_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_bwd_finalize: bad sizes");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(spk_ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
-                       count, gamma, invstd, dgamma, dbeta, coef, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    if (spk_bn_finalize_workspace(nblk, C)) {
+        SPK_REQUIRE(ws, "spk_bn_bwd_finalize: %d partial rows need the fp64 workspace", nblk);
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
+        SPK_LAUNCH_CHECK("spk_bn_bwd_finalize(fold)");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
+                           gamma, invstd, dgamma, dbeta, coef, accumulate);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
+                           invstd, dgamma, dbeta, coef, accumulate);
+    }
     SPK_LAUNCH_CHECK("spk_bn_bwd_finalize");
     return 0;
 }

@@ -37,14 +37,17 @@ struct ConvArgs {
     int IS, OS, ooy, oox;
     int TH, TW, tiles_y, tiles_x;
     int halo_h, halo_w, min_dy, min_dx;
+    unsigned halo_w_magic;   // ceil(2^32 / halo_w): p / halo_w == umulhi(p, magic) for p * halo_w < 2^32
     int ntaps, ncg, nblocks, flags;
-    signed char tap_dy[12], tap_dx[12], tap_w[12];
+    int tap_off[9];   // LDS offset (float4 units) of the tap inside the halo tile
+    int tap_w[9];     // weight tap index
 };
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
     // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int ly = qq / a.TW, lx = qq - ly * a.TW;
         const int oy = oy0 + ly, ox = ox0 + lx;
         v = v && oy < a.OH && ox < a.OW;
-        lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LPS + h * 4;
+        lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * (LPS / 4) + h;   // float4 units
         obase[i] = v ? ((b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox) * a.Cout + n0 : -1;
     }
 
@@ -102,49 +105,99 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 sc = *(const f32x4*)(a.in_scale + c);
                 sh = *(const f32x4*)(a.in_shift + c);
             }
-            int p = tid >> 3;
-            int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-            for (; p < halo_pix; p += 32) {
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-                    v = *(const f32x4*)(a.in + (size_t)((b * a.IH + iy) * a.IW + ix) * a.Cin + c);
-                    if (flags & SPK_IN_AFFINE_RELU) {
-                        v = v * sc + sh;
-                        v[0] = fmaxf(v[0], 0.f);
-                        v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f);
-                        v[3] = fmaxf(v[3], 0.f);
-                    }
+            // U independent 16-byte loads in flight per thread (addresses clamped, zero selected afterwards: no branch
+            // around a load, so the compiler issues the whole batch before the first wait)
+            constexpr int U = 4;
+            for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
+                f32x4 v[U];
+                bool inb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int p = base + 32 * u;
+                    p = p < halo_pix ? p : halo_pix - 1;
+                    const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                    const int hx = p - hy * a.halo_w;
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                    const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                    v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c);
                 }
-                *(f32x4*)(lds + p * LPS + quad * 4) = v;
-                hx += 32;
-                while (hx >= a.halo_w) {
-                    hx -= a.halo_w;
-                    ++hy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = base + 32 * u;
+                    f32x4 w = v[u];
+                    if (flags & SPK_IN_AFFINE_RELU) {
+                        w = w * sc + sh;
+                        w[0] = fmaxf(w[0], 0.f);
+                        w[1] = fmaxf(w[1], 0.f);
+                        w[2] = fmaxf(w[2], 0.f);
+                        w[3] = fmaxf(w[3], 0.f);
+                    }
+                    if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (p < halo_pix) *(f32x4*)(lds + p * LPS + quad * 4) = w;
                 }
             }
         }
         __syncthreads();
 
+        // K loop over (tap, 8-cin group), software-pipelined one group ahead: while the 4*MT*NT MFMAs of a group
+        // issue (>= 1 k cycles), the B fragments (L2 -> VGPR) and A fragments (LDS -> VGPR) of the next group are
+        // already in flight, and the next tap's table entries (scalar loads) are fetched a whole tap early, so the
+        // matrix pipe never waits on a memory round trip inside a wave.
+        const f32x4* lds4 = (const f32x4*)lds;
+        const float* wbase = a.wpk + ((size_t)(ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
+        const size_t tap_stride = (size_t)(a.Cin >> 3) * cout32 * 256;
+        const size_t grp_stride = (size_t)cout32 * 256;
+        auto load_b = [&](f32x4* bf, int tw, int g) {
+            const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + j * 256);
+        };
+        auto load_a = [&](f32x4* af, int toff4, int g) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = lds4[lbase[i] + toff4 + g * 2];
+        };
+        auto mma = [&](const f32x4* af, const f32x4* bf) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        };
+        f32x4 b0[NT], b1[NT], a0[MT], a1[MT];
+        int tw = a.tap_w[0], toff = a.tap_off[0];
+        load_b(b0, tw, 0);
+        load_a(a0, toff, 0);
         for (int t = 0; t < a.ntaps; ++t) {
-            const int toff = ((a.tap_dy[t] - a.min_dy) * a.halo_w + (a.tap_dx[t] - a.min_dx)) * LPS;
-            const float* wp = a.wpk + ((size_t)(a.tap_w[t] * (a.Cin >> 3) + ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 bf[NT], af[MT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + ((size_t)g * cout32 + j) * 256);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *(const f32x4*)(lds + lbase[i] + toff + g * 8);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            const bool more = t + 1 < a.ntaps;
+            const int tn = more ? t + 1 : t;
+            const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn];
+            load_b(b1, tw, 1);
+            load_a(a1, toff, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(b0, tw, 2);
+            load_a(a0, toff, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(b1, tw, 3);
+            load_a(a1, toff, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                load_b(b0, tw_n, 0);
+                load_a(a0, toff_n, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            tw = tw_n;
+            toff = toff_n;
         }
     }
 
@@ -248,7 +301,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     for (int t = 0; t < ntaps; ++t) {
         SPK_REQUIRE(tap_dy[t] >= -8 && tap_dy[t] <= 8 && tap_dx[t] >= -8 && tap_dx[t] <= 8 && tap_w[t] >= 0 && tap_w[t] < 9,
                     "spk_conv_mfma: tap %d out of range", t);
-        a.tap_dy[t] = (signed char)tap_dy[t]; a.tap_dx[t] = (signed char)tap_dx[t]; a.tap_w[t] = (signed char)tap_w[t];
+        a.tap_w[t] = tap_w[t];
         if (tap_dy[t] < mindy) mindy = tap_dy[t];
         if (tap_dy[t] > maxdy) maxdy = tap_dy[t];
         if (tap_dx[t] < mindx) mindx = tap_dx[t];
@@ -257,6 +310,8 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.min_dy = mindy; a.min_dx = mindx;
     a.halo_h = (TH - 1) * IS + (maxdy - mindy) + 1;
     a.halo_w = (TW - 1) * IS + (maxdx - mindx) + 1;
+    for (int t = 0; t < ntaps; ++t) a.tap_off[t] = ((tap_dy[t] - mindy) * a.halo_w + (tap_dx[t] - mindx)) * (LPS / 4);
+    a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
     a.ntaps = ntaps; a.ncg = Cout / (32 * NT);
     a.nblocks = B * a.tiles_y * a.tiles_x * a.ncg;
     a.flags = flags;

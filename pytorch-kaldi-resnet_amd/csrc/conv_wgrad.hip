@@ -21,13 +21,15 @@ struct WgradArgs {
     int S, KW, pad;
     int TH, TW, tiles_y, tiles_x, nregions, nsplit;
     int halo_h, halo_w;
+    unsigned halo_w_magic, tw_magic;   // ceil(2^32 / d) for exact small-range division
     int flags;
 };
 
 template <int NTAPS, int WK, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar registers, scalar branches
     const int r = lane & 31, h = lane >> 5;
     const int wk = wave / WN, wn = wave % WN;
     const int ci0 = blockIdx.y * 32;
@@ -44,9 +46,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    int toff[NTAPS];
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t) toff[t] = ((t / a.KW) * a.halo_w + (t % a.KW)) * 32;
+    constexpr int KS = (NTAPS == 9) ? 3 : 1;   // kernel size
+    const int row_stride = a.halo_w * 32;      // floats between two halo rows
 
     const int quad = tid & 7;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -66,68 +67,103 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         const int oy0 = ty * a.TH, ox0 = tx * a.TW;
         const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
         __syncthreads();  // previous region fully consumed
-        {   // X halo tile, 32 channels, optional fused BN+ReLU of the producing layer
-            int p = tid >> 3;
-            int hy = p / a.halo_w, hx = p - hy * a.halo_w;
-            for (; p < halo_pix; p += 32) {
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-                    v = *(const f32x4*)(a.x + (size_t)((b * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + quad * 4);
-                    if (flags & SPK_IN_AFFINE_RELU) {
-                        v = v * sc + sh;
-                        v[0] = fmaxf(v[0], 0.f);
-                        v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f);
-                        v[3] = fmaxf(v[3], 0.f);
-                    }
+        {   // X halo tile, 32 channels, optional fused BN+ReLU of the producing layer; U loads in flight per thread
+            constexpr int U = 4;
+            for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
+                f32x4 v[U];
+                bool inb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int p = base + 32 * u;
+                    p = p < halo_pix ? p : halo_pix - 1;
+                    const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                    const int hx = p - hy * a.halo_w;
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                    const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                    v[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
                 }
-                *(f32x4*)(xs + p * 32 + quad * 4) = v;
-                hx += 32;
-                while (hx >= a.halo_w) {
-                    hx -= a.halo_w;
-                    ++hy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = base + 32 * u;
+                    f32x4 w = v[u];
+                    if (flags & SPK_IN_AFFINE_RELU) {
+                        w = w * sc + sh;
+                        w[0] = fmaxf(w[0], 0.f);
+                        w[1] = fmaxf(w[1], 0.f);
+                        w[2] = fmaxf(w[2], 0.f);
+                        w[3] = fmaxf(w[3], 0.f);
+                    }
+                    if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (p < halo_pix) *(f32x4*)(xs + p * 32 + quad * 4) = w;
                 }
             }
         }
         {   // dY tile: zero outside the image, so border pixels contribute nothing
             constexpr int QPP = WN * 8;         // float4 quads per pixel
             constexpr int PSTEP = 256 / QPP;    // pixels per pass
+            constexpr int U = 4;
             const int cq = tid % QPP;
-            int p = tid / QPP;
-            int ly = p / a.TW, lx = p - ly * a.TW;
-            for (; p < npix; p += PSTEP) {
-                const int oy = oy0 + ly, ox = ox0 + lx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (oy < a.OH && ox < a.OW)
-                    v = *(const f32x4*)(a.dy + (size_t)((b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + cq * 4);
-                *(f32x4*)(dys + p * (WN * 32) + cq * 4) = v;
-                lx += PSTEP;
-                while (lx >= a.TW) {
-                    lx -= a.TW;
-                    ++ly;
+            for (int base = tid / QPP; base < npix; base += PSTEP * U) {
+                f32x4 v[U];
+                bool inb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int p = base + PSTEP * u;
+                    p = p < npix ? p : npix - 1;
+                    const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+                    const int lx = p - ly * a.TW;
+                    const int oy = oy0 + ly, ox = ox0 + lx;
+                    inb[u] = oy < a.OH && ox < a.OW;
+                    const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
+                    v[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = base + PSTEP * u;
+                    f32x4 w = inb[u] ? v[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (p < npix) *(f32x4*)(dys + p * (WN * 32) + cq * 4) = w;
                 }
             }
         }
         __syncthreads();
 
-        int kk = wk;
-        int qy = kk / half_w, j = kk - qy * half_w;
-        for (; kk < ksteps; kk += WK) {
+        // k-steps of this wave: kk = wk, wk + WK, ...; operands of step i+1 are read from LDS while the NTAPS MFMAs
+        // of step i issue (ping-pong register sets), so the matrix pipe does not wait on LDS latency.
+        const int nsteps = (ksteps - wk + WK - 1) / WK;
+        int qy = wk / half_w, j = wk - qy * half_w;   // position of the next step to load
+        auto load_step = [&](float& bval, float* av) {
             const int qx = 2 * j + h;
-            const float bval = dys[(qy * a.TW + qx) * (WN * 32) + wn * 32 + r];
+            bval = dys[(qy * a.TW + qx) * (WN * 32) + wn * 32 + r];
             const int xb = ((qy * a.S) * a.halo_w + qx * a.S) * 32 + r;
-            float av[NTAPS];
+            // taps of one kernel row are 32 floats apart: the compiler pairs them into ds_read2_b32
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) av[t] = xs[xb + toff[t]];
+            for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bval, acc[t], 0, 0, 0);
+                for (int kw = 0; kw < KS; ++kw) av[kh * KS + kw] = xs[xb + kh * row_stride + kw * 32];
             j += WK;
             while (j >= half_w) {
                 j -= half_w;
                 ++qy;
             }
+        };
+        auto mma = [&](float bval, const float* av) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bval, acc[t], 0, 0, 0);
+        };
+        float bv0, bv1, av0[NTAPS], av1[NTAPS];
+        if (nsteps > 0) load_step(bv0, av0);
+        for (int i = 0; i < nsteps; i += 2) {
+            const bool has1 = i + 1 < nsteps;
+            if (has1) load_step(bv1, av1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(bv0, av0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < nsteps) load_step(bv0, av0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) mma(bv1, av1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -222,6 +258,8 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     if (nsplit > a.nregions) nsplit = a.nregions;
     a.nsplit = nsplit;
     a.halo_h = (TH - 1) * stride + ksize; a.halo_w = (TW - 1) * stride + ksize;
+    a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
+    a.tw_magic = (unsigned)((0x100000000ULL + (unsigned long long)TW - 1) / (unsigned long long)TW);
     a.flags = flags;
     const int ntaps = ksize * ksize;
     const int WK = 4 / WN;

@@ -28,11 +28,11 @@ _SIGS = {
     "spk_stem_conv_wgrad": [_P] * 4 + [_I] * 4 + [_P],
     "spk_bn_stats_blocks": [_L, _I],
     "spk_bn_stats_partial": [_P, _P, _L, _I, _P],
-    "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P],
+    "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P, _P],
     "spk_bn_eval_coeffs": [_P] * 6 + [_I, _F, _P],
     "spk_bn_apply": [_P] * 7 + [_L, _I, _I, _P],
     "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P],
-    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P],
+    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P],
     "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P],
     "spk_stats_pool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -64,6 +64,8 @@ def lib():
         l.spk_version.restype = ctypes.c_int
         l.spk_conv_wgrad_workspace.restype = ctypes.c_size_t
         l.spk_conv_wgrad_workspace.argtypes = [_I, _I, _I, _I]
+        l.spk_bn_finalize_workspace.restype = ctypes.c_size_t
+        l.spk_bn_finalize_workspace.argtypes = [_I, _I]
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.argtypes = sig
@@ -73,7 +75,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["spk_version", "spk_last_error", "spk_conv_wgrad_workspace"] + list(_SIGS)
+    return ["spk_version", "spk_last_error", "spk_conv_wgrad_workspace", "spk_bn_finalize_workspace"] + list(_SIGS)
 
 
 def ptr(t):

@@ -197,11 +197,24 @@ def bn_stats_partial(x2d):
     return part
 
 
+_ws64_cache = {}
+
+
+def _ws64(device):
+    """fp64 scratch for the two-stage BN finalize: 64 rows x 1024 channels x 2 doubles is the maximum."""
+    w = _ws64_cache.get(str(device))
+    if w is None:
+        w = torch.empty(64 * 1024 * 2, device=device, dtype=torch.float64)
+        _ws64_cache[str(device)] = w
+    return w
+
+
 def bn_finalize(partial, count, gamma, beta, running_mean, running_var, nbt, out4):
     """out4: tensor [4][C] = (mean, invstd, scale, shift)."""
     C = gamma.numel()
     call("spk_bn_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
-         ptr(running_var), ptr(nbt), ptr(out4[0]), ptr(out4[1]), ptr(out4[2]), ptr(out4[3]), BN_MOMENTUM, BN_EPS, stream())
+         ptr(running_var), ptr(nbt), ptr(out4[0]), ptr(out4[1]), ptr(out4[2]), ptr(out4[3]), BN_MOMENTUM, BN_EPS,
+         ptr(_ws64(partial.device)), stream())
 
 
 def bn_eval_coeffs(gamma, beta, rm, rv, out2):
@@ -231,7 +244,7 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
          N, C, mask_mode, stream())
     call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
-         1 if accumulate else 0, stream())
+         1 if accumulate else 0, ptr(_ws64(raw.device)), stream())
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),

@@ -12,8 +12,39 @@ LDS_SOFT = 52 * 1024      # 3 blocks / CU
 LDS_HARD = 80 * 1024      # 2 blocks / CU
 
 
-@lru_cache(maxsize=None)
+# Measured overrides (tools/conv_bench.py --sweep on MI355X): key -> (TH, TW, MT, NT) / (TH, TW, WN)
+FORCE_CONV = {}
+FORCE_WGRAD = {}
+
+
+def _load_table():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+    if os.path.exists(path):
+        t = json.load(open(path))
+        for k, v in t.get("conv", {}).items():
+            FORCE_CONV[tuple(int(x) for x in k.split(","))] = tuple(v)
+        for k, v in t.get("wgrad", {}).items():
+            FORCE_WGRAD[tuple(int(x) for x in k.split(","))] = tuple(v)
+
+
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
+    key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
+    if key in FORCE_CONV:
+        return FORCE_CONV[key]
+    return _conv_tile(*key)
+
+
+def wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
+    key = (OH, OW, Cin, Cout, ksize, stride)
+    if key in FORCE_WGRAD:
+        return FORCE_WGRAD[key]
+    return _wgrad_tile(*key)
+
+
+@lru_cache(maxsize=None)
+def _conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
     """-> (TH, TW, MT, NT).  kspan = max tap offset - min tap offset + 1 per axis."""
     NT = 1 if Cout % 64 else 2
     best = None
@@ -48,7 +79,7 @@ def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
 
 
 @lru_cache(maxsize=None)
-def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, nregions_per_image_hint=0):
+def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
     """-> (TH, TW, WN).  TW even; LDS = X halo (128 B/pixel) + dY tile (WN*128 B/pixel) <= 72 KiB."""
     WN = 1 if Cout == 32 else 2
     best = None
@@ -72,3 +103,6 @@ def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, nregions_per_image_hint=0):
 def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=768):
     per = (Cin // 32) * (Cout // (32 * WN))
     return max(1, min(nregions, target_blocks // per))
+
+
+_load_table()

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Micro-benchmark / tile sweep of the MFMA conv kernels on the ResNet-34 layer shapes (GPU box).
+
+  python tools/conv_bench.py            # time every conv launch shape of one training step with the current tiles
+  python tools/conv_bench.py --sweep    # try candidate tiles per shape, print the best and write tile_table.json
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pytorch_kaldi_resnet_amd  # noqa: E402,F401
+from pytorch_kaldi_resnet_amd import ops, tiling  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--feat", type=int, default=80)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--out", default=os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "tile_table.json"))
+args = ap.parse_args()
+B, F, T = args.batch, args.feat, args.frames
+dev = "cuda"
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# (name, Cin, Cout, H, W, k, stride): the distinct conv shapes of ResNet-34 at [B, 80, 300]
+H1, W1 = F, T
+shapes = []
+dims = [(32, H1, W1)]
+for c in (64, 128, 256):
+    h, w = dims[-1][1], dims[-1][2]
+    dims.append((c, (h - 1) // 2 + 1, (w - 1) // 2 + 1))
+for i, (c, h, w) in enumerate(dims):
+    shapes.append(("L%d 3x3 s1" % (i + 1), c, c, h, w, 3, 1))
+    if i > 0:
+        pc, ph, pw = dims[i - 1]
+        shapes.append(("L%d 3x3 s2" % (i + 1), pc, c, ph, pw, 3, 2))
+        shapes.append(("L%d 1x1 s2" % (i + 1), pc, c, ph, pw, 1, 2))
+
+
+def conv_candidates(OH, OW, IS, ks, Cout):
+    cands = set()
+    for MT in (1, 2, 3, 4):
+        cap = 128 * MT
+        for NT in (1, 2, 4):
+            if Cout % (32 * NT):
+                continue
+            if MT * NT > 8:
+                continue
+            best = []
+            for TH in range(1, min(OH, cap) + 1):
+                for TW in range(1, min(OW, cap // TH) + 1):
+                    halo = ((TH - 1) * IS + ks) * ((TW - 1) * IS + ks)
+                    if halo * 144 > 150 * 1024:
+                        continue
+                    ty, tx = -(-OH // TH), -(-OW // TW)
+                    util = OH * OW / (ty * tx * cap)
+                    best.append((-util, halo / (TH * TW), TH, TW))
+            best.sort()
+            for u, hr, TH, TW in best[:6]:
+                cands.add((TH, TW, MT, NT))
+    return sorted(cands)
+
+
+table = {"conv": {}, "wgrad": {}}
+rows = []
+for name, Cin, Cout, H, W, k, s in shapes:
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
+    wpk = ops.pack_conv_weight(w)
+    wpk_t = ops.pack_conv_weight(w, True)
+    OH, OW = ops.conv_out_hw(H, W, k, s)
+    dy = torch.randn(B, OH, OW, Cout, device=dev)
+    dw = torch.empty_like(w)
+    out = torch.empty(B, OH, OW, Cout, device=dev)
+    dx = torch.empty(B, H, W, Cin, device=dev)
+    flops = 2.0 * B * OH * OW * Cout * Cin * k * k
+    key = (OH, OW, s, k, k, k * k, Cout)
+    if args.sweep:
+        res = []
+        for cand in conv_candidates(OH, OW, s, k, Cout):
+            tiling.FORCE_CONV[key] = cand
+            try:
+                ms = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
+            except RuntimeError as e:
+                continue
+            res.append((ms, cand))
+        res.sort()
+        tiling.FORCE_CONV[key] = res[0][1]
+        table["conv"][",".join(map(str, key))] = list(res[0][1])
+        print("%-12s fwd best %s %.3f ms %.1f TF | top: %s" % (name, res[0][1], res[0][0], flops / res[0][0] / 1e9,
+              " ".join("%s:%.3f" % (c, m) for m, c in res[:5])), flush=True)
+        if s == 1 and k == 3:
+            # the stride-1 data gradient is the same launch shape with Cin/Cout swapped (equal here)
+            pass
+    t_fwd = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
+    t_dg = timeit(lambda: ops.conv_dgrad(dy, wpk_t, Cin, k, s, (H, W), out=dx), args.reps)
+    t_wg = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
+    rows.append((name, flops, t_fwd, t_dg, t_wg))
+    print("%-12s %6.1f GF  fwd %.3f ms %5.1f TF  dgrad %.3f ms %5.1f TF  wgrad %.3f ms %5.1f TF   tiles %s / %s" % (
+        name, flops / 1e9, t_fwd, flops / t_fwd / 1e9, t_dg, flops / t_dg / 1e9, t_wg, flops / t_wg / 1e9,
+        tiling.conv_tile(*key), tiling.wgrad_tile(OH, OW, Cin, Cout, k, s)), flush=True)
+if args.sweep:
+    json.dump(table, open(args.out, "w"), indent=1)
+    print("wrote", args.out)
