@@ -155,13 +155,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         partial[(size_t)blockIdx.x * (STEM_C * 9) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nblk,
-                                         int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= STEM_C * 9) return;
+// one block per weight element: 256 threads fold the per-block partials in fp64, fixed order
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                int nblk, int accumulate) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += (double)partial[(size_t)k * (STEM_C * 9) + i];
-    dw[i] = accumulate ? dw[i] + (float)s : (float)s;
+    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * (STEM_C * 9) + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[i] = accumulate ? dw[i] + (float)red[0] : (float)red[0];
 }
 
 extern "C" int spk_stem_wgrad_blocks(int B, int F, int T) {
@@ -177,7 +184,7 @@ extern "C" int spk_stem_conv_wgrad(const float* x, const float* draw, float* dw,
     const int nblk = spk_stem_wgrad_blocks(B, F, T);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, draw, partial, B, F, T);
     SPK_LAUNCH_CHECK("spk_stem_conv_wgrad");
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, partial, dw, nblk, accumulate);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(STEM_C * 9), dim3(256), 0, (hipStream_t)stream, partial, dw, nblk, accumulate);
     SPK_LAUNCH_CHECK("spk_stem_wgrad_reduce");
     return 0;
 }

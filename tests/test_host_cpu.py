@@ -1,0 +1,206 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host I/O and scoring
+against the reference-generated fixtures, the NeuralSpeakerModel boundary (state_dict naming, loadParameters
+semantics, flat arenas), optimizer (de)serialisation, tile selection invariants."""
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_kaldi_resnet_amd  # noqa: F401
+from pytorch_kaldi_resnet_amd import datasets, hip, kaldi_io, scoring, tiling
+from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+from pytorch_kaldi_resnet_amd.optim import FlatSGD, cosine_lr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "spkhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(spk_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    lib = hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), "libspkhip.so does not export %s" % name
+    assert sorted(hip.exported_symbols()) == declared
+    assert lib.spk_version() >= 100
+    # argument validation happens on the host before any launch: no GPU needed to see the error convention
+    rc = lib.spk_sgd_step(None, None, None, 0, 0.1, 0.9, 0.0, 1.0, 1, None)
+    assert rc < 0 and b"spk_sgd_step" in lib.spk_last_error()
+
+
+def test_kaldi_io_reads_reference_written_ark(gold_dir):
+    d = os.path.join(gold_dir, "io")
+    exp = np.load(os.path.join(d, "feats_expected.npz"))
+    cwd = os.getcwd()
+    os.chdir(ROOT)   # scp paths are relative to the repository root
+    try:
+        n = 0
+        for key, mat in kaldi_io.read_mat_scp(os.path.join(d, "feats.scp")):
+            np.testing.assert_array_equal(mat, exp[key])
+            n += 1
+        assert n == 6
+        got = dict(kaldi_io.read_mat_ark(os.path.join(d, "feats.ark")))
+        assert sorted(got) == sorted(exp.files)
+    finally:
+        os.chdir(cwd)
+
+
+def test_kaldi_io_round_trips(tmp_path):
+    m32 = np.random.RandomState(0).randn(7, 5).astype(np.float32)
+    m64 = np.random.RandomState(1).randn(3, 4)
+    p = str(tmp_path / "a.ark")
+    with open(p, "wb") as f:
+        o1 = kaldi_io.write_mat(f, m32, key="u1")
+        o2 = kaldi_io.write_mat(f, m64, key="u2")
+    np.testing.assert_array_equal(kaldi_io.read_mat("%s:%d" % (p, o1)), m32)
+    np.testing.assert_array_equal(kaldi_io.read_mat("ark:%s:%d" % (p, o2)), m64)
+    assert [k for k, _ in kaldi_io.read_mat_ark(p)] == ["u1", "u2"]
+    v = np.arange(5, dtype=np.float32)
+    q = str(tmp_path / "v.ark")
+    with open(q, "wb") as f:
+        kaldi_io.write_vec_flt(f, v, key="x")
+    (k, r), = list(kaldi_io.read_vec_flt_ark(q))
+    assert k == "x"
+    np.testing.assert_array_equal(r, v)
+    # empty ark, text matrix
+    open(str(tmp_path / "e.ark"), "wb").close()
+    assert list(kaldi_io.read_mat_ark(str(tmp_path / "e.ark"))) == []
+    t = kaldi_io.read_mat(io.BytesIO(b" [\n 1 2 3\n 4 5 6 ]\n"))
+    np.testing.assert_array_equal(t, np.array([[1, 2, 3], [4, 5, 6]], np.float32))
+    with pytest.raises(kaldi_io.UnknownHeader):
+        kaldi_io.read_mat(io.BytesIO(b"\0BXX \x04\x00\x00\x00\x00"))
+
+
+def test_compressed_matrix_decode():
+    # hand-built 'CM ' matrix: 2 columns, 3 rows
+    import struct
+    vmin, vrange, rows, cols = -1.0, 4.0, 3, 2
+    hdr = np.array([[0, 16384, 49152, 65535], [0, 0, 65535, 65535]], dtype="<u2")
+    data = np.array([[0, 64, 255], [10, 128, 192]], dtype=np.uint8)
+    buf = b"\0BCM " + struct.pack("<ffii", vmin, vrange, rows, cols) + hdr.tobytes() + data.tobytes()
+    m = kaldi_io.read_mat(io.BytesIO(buf))
+    assert m.shape == (3, 2)
+    q = vmin + vrange * 1.52590218966964e-05 * hdr.astype(np.float64)
+    assert abs(m[0, 0] - q[0, 0]) < 1e-6 and abs(m[1, 0] - q[0, 1]) < 1e-6 and abs(m[2, 0] - q[0, 3]) < 1e-6
+    assert abs(m[1, 1] - (q[1, 1] + (q[1, 2] - q[1, 1]) * 64 / 128.0)) < 1e-5
+
+
+def test_scoring_matches_reference_outputs(gold_dir, tmp_path):
+    d = os.path.join(gold_dir, "io")
+    mean = scoring.compute_mean(os.path.join(d, "emb.iv"), str(tmp_path / "mean.vec"))
+    ref_mean = kaldi_io.read_vec_flt(os.path.join(d, "mean.vec"))
+    np.testing.assert_allclose(mean, ref_mean, rtol=1e-6, atol=1e-7)
+    assert open(str(tmp_path / "mean.vec")).read().split() == open(os.path.join(d, "mean.vec")).read().split()
+    emb = scoring.read_embeddings(os.path.join(d, "emb.iv"))
+    scores, labels = scoring.cosine_score(emb, emb, os.path.join(d, "trials"), ref_mean, str(tmp_path / "scores"))
+    ref = [float(l.split()[2]) for l in open(os.path.join(d, "scores"))]
+    np.testing.assert_allclose(scores, ref, rtol=1e-6, atol=2e-7)
+    assert "{0:.2%}".format(scoring.compute_eer(ref, labels)) == open(os.path.join(d, "eer.txt")).read().strip()
+    # degenerate inputs: perfectly separable and perfectly wrong
+    assert scoring.compute_eer([0.9, 0.8, 0.1, 0.0], [1, 1, 0, 0]) == 0.0
+    assert scoring.compute_eer([0.0, 0.1, 0.8, 0.9], [1, 1, 0, 0]) == 1.0
+
+
+def test_datasets_balance_and_crop(gold_dir, tmp_path):
+    d = os.path.join(gold_dir, "io")
+    u2s = str(tmp_path / "utt2spkid")
+    utts = [l.split()[0] for l in open(os.path.join(d, "feats.scp"))]
+    # speaker 0 has 2 utts, speaker 1 has 4 -> cap = min(500, (4+1)//2) = 2 -> rep(spk0) = 1, rep(spk1) = max(1, 2//4) = 1
+    with open(u2s, "w") as f:
+        for i, u in enumerate(utts):
+            f.write("%s %d\n" % (u, 0 if i < 2 else 1))
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ds = datasets.SequenceDataset(os.path.join(d, "feats.scp"), u2s, [16])
+        assert len(ds) == 6
+        np.random.seed(0)
+        x, y = ds[3]
+        assert x.shape == (8, 16) and x.dtype == np.float32 and int(y) == 1 and x.flags["C_CONTIGUOUS"]
+        ds2 = datasets.SequenceDataset2(os.path.join(d, "feats.scp"), u2s, 12)
+        assert len(ds2) == 2 * 2 and ds2[1][0].shape == (8, 12)
+        ed = datasets.EmbeddingDataset(os.path.join(d, "feats.scp"))
+        x, utt = ed[2]
+        assert utt == utts[2] and x.shape == (8, 26)
+        with pytest.raises(AssertionError):
+            datasets.SequenceDataset(os.path.join(d, "feats.scp"), u2s, [999])[0]
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize("loss,arch", [("AAM", "resnet34"), ("softmax", "resnet34"), ("AAM-v1", "resnet34"),
+                                       ("AAM", "resnet101")])
+def test_state_dict_matches_reference_keys(gold_dir, loss, arch):
+    keys = json.load(open(os.path.join(gold_dir, "state_keys_%s_%s.json" % (arch, loss))))
+    m = NeuralSpeakerModel(7, 80, "mean+std", loss, arch=arch)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _ in keys]
+    assert [list(v.shape) for v in sd.values()] == [s for _, s in keys]
+    if arch == "resnet34":
+        assert len(sd) == {"AAM": 219, "softmax": 225, "AAM-v1": 224}[loss]
+
+
+def test_flat_arena_and_load_parameters(capsys):
+    m = NeuralSpeakerModel(5, 40, "mean", "softmax")
+    flat = m.flat_parameters()
+    assert flat.numel() >= sum(p.numel() for p in m.parameters())
+    for p, o in zip(m.parameters(), m._offsets):
+        assert p.data_ptr() == flat.data_ptr() + 4 * o and o % 4 == 0
+    # parameters are views: writing the arena changes the parameter
+    flat.zero_()
+    assert float(m.fc1.weight.abs().sum()) == 0.0
+    # loadParameters: 'module.' prefix stripped, unknown and mismatching entries reported and skipped
+    st = {"module." + k: torch.ones_like(v) for k, v in m.state_dict().items()}
+    st["module.bogus"] = torch.zeros(1)
+    st["module.last.weight"] = torch.zeros(3, 256)
+    m.loadParameters(st)
+    out = capsys.readouterr().out
+    assert "module.bogus is not in the model." in out
+    assert "Wrong parameter length: module.last.weight" in out
+    assert float(m.fc1.weight.min()) == 1.0 and float(m.last.weight.abs().sum()) == 0.0
+    assert float(flat[:10].sum()) == 10.0     # still the same arena
+    with pytest.raises(RuntimeError):
+        m.predict(torch.zeros(1, 40, 64))     # no CPU path
+    with pytest.raises(NotImplementedError):
+        NeuralSpeakerModel(5, 40, "mean", "nope")
+
+
+def test_flat_sgd_state_dict_speaks_torch_sgd():
+    m = NeuralSpeakerModel(4, 40, "mean", "AAM")
+    opt = FlatSGD(m, 0.1, momentum=0.9, weight_decay=5e-4)
+    ref = torch.optim.SGD(m.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    opt.load_state_dict(sd)
+    back = opt.state_dict()
+    assert set(back["state"].keys()) == set(sd["state"].keys())
+    for k in sd["state"]:
+        assert torch.equal(back["state"][k]["momentum_buffer"], sd["state"][k]["momentum_buffer"])
+    assert back["param_groups"][0]["lr"] == 0.1 and back["param_groups"][0]["params"] == sd["param_groups"][0]["params"]
+    ref2 = torch.optim.SGD(m.parameters(), 0.5)
+    ref2.load_state_dict(back)               # torch accepts what FlatSGD emits
+    assert ref2.param_groups[0]["momentum"] == 0.9
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 30, eta_min=1e-4)
+    for e in range(5):
+        assert abs(opt.param_groups[0]["lr"] - cosine_lr(e, 30, 0.1, 1e-4)) < 1e-9
+        sch.step()
+
+
+@pytest.mark.parametrize("shape", [(80, 300), (40, 150), (20, 75), (10, 38), (10, 25), (5, 13), (1, 1), (80, 1000), (3, 7)])
+def test_tile_selection_invariants(shape):
+    OH, OW = shape
+    for IS, ks, ntaps in [(1, 3, 9), (2, 3, 9), (2, 1, 1), (1, 1, 1), (1, 2, 4)]:
+        for Cout in (32, 64, 256):
+            TH, TW, MT, NT = tiling.conv_tile(OH, OW, IS, ks, ks, ntaps, Cout)
+            assert 1 <= TH and 1 <= TW and TH * TW <= 128 * MT and MT in (1, 2, 3, 4) and Cout % (32 * NT) == 0
+            assert ((TH - 1) * IS + ks) * ((TW - 1) * IS + ks) * 144 <= 160 * 1024
+    for k, s in [(3, 1), (3, 2), (1, 2), (1, 1)]:
+        TH, TW, WN = tiling.wgrad_tile(OH, OW, 64, 64, k, s)
+        assert TW % 2 == 0 and WN in (1, 2, 4)
+        assert (((TH - 1) * s + k) * ((TW - 1) * s + k) + TH * TW * WN) * 128 <= 160 * 1024

@@ -1,0 +1,104 @@
+"""BASELINE configs[0]-shaped plumbing on the GPU: synthetic fbank ark/scp -> SequenceDataset/DataLoader ->
+scripts/train_resnet.py (2 epochs) -> checkpoint -> scripts/decode.py -> compute_mean / cosine_score /
+compute_eer, with the extracted embeddings compared against the CPU oracle loaded from the same checkpoint
+(cosine >= 1 - 1e-4, the BASELINE bar) and the EER compared against the oracle's embeddings' EER."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_data(d, n_spk=5, per_spk=12, feat=80):
+    import pytorch_kaldi_resnet_amd  # noqa: F401
+    from pytorch_kaldi_resnet_amd import kaldi_io
+    rs = np.random.RandomState(1234)
+    spk_mean = 0.5 * rs.randn(n_spk, feat).astype(np.float32)
+    scp, u2s = [], []
+    with open(os.path.join(d, "feats.ark"), "wb") as f:
+        for s in range(n_spk):
+            for u in range(per_spk):
+                utt = "spk%02d-utt%02d" % (s, u)
+                T = 208 if u < per_spk - 2 else 232      # decode set: equal-length batches + a different length
+                mat = (rs.randn(T, feat).astype(np.float32) + spk_mean[s])
+                off = kaldi_io.write_mat(f, mat, key=utt)
+                scp.append("%s %s:%d" % (utt, os.path.join(d, "feats.ark"), off))
+                u2s.append("%s %d" % (utt, s))
+    open(os.path.join(d, "train.scp"), "w").write("\n".join(scp[:-10]) + "\n")
+    open(os.path.join(d, "cv.scp"), "w").write("\n".join(scp[-10:]) + "\n")
+    open(os.path.join(d, "decode.scp"), "w").write("\n".join(scp) + "\n")
+    open(os.path.join(d, "utt2spkid"), "w").write("\n".join(u2s) + "\n")
+    return n_spk
+
+
+def test_train_decode_score_pipeline(tmp_path):
+    d = str(tmp_path)
+    n_spk = _make_data(d)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    log = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_resnet.py"), "--gpu", "0", "--workers", "0",
+                          "--batch-size", "16", "--print-freq", "1", "--arch", "resnet34", "--input-dim", "80",
+                          "--loss-type", "AAM", "--pooling", "mean+std", "--margin", "0.2", "--scale", "30", "--epochs", "2",
+                          "--lr", "0.01", "--lr-final", "0.001", "--wd", "5e-4", "--max-chunk-size", "200",
+                          "--train-list", os.path.join(d, "train.scp"), "--cv-list", os.path.join(d, "cv.scp"),
+                          "--spk-num", str(n_spk), "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "7",
+                          "--log-dir", os.path.join(d, "exp")], env=env, capture_output=True, text=True, timeout=600)
+    assert log.returncode == 0, log.stdout[-3000:] + log.stderr[-3000:]
+    assert "Epoch: [1][" in log.stdout and " * Acc@1 " in log.stdout
+    # model_best.pth.tar only appears once cv Acc@1 > 0 (reference semantics: is_best = acc1 > best_acc1 = 0)
+    ckpt_path = os.path.join(d, "exp", "checkpoint_epoch1.pth.tar")
+    assert os.path.exists(ckpt_path) and os.path.exists(os.path.join(d, "exp", "checkpoint_epoch0.pth.tar"))
+    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"epoch", "arch", "state_dict", "best_acc1", "optimizer"} and len(ckpt["state_dict"]) == 219
+    dec = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "decode.py"), "--gpu", "0", "--workers", "0",
+                          "--batch-size", "1", "--chunk-size", "-1", "--spk_num", str(n_spk), "--arch", "resnet34",
+                          "--input-dim", "80", "--pooling", "mean+std", "--model-path", ckpt_path,
+                          "--decode-scp", os.path.join(d, "decode.scp"), "--out-path", os.path.join(d, "emb")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert dec.returncode == 0, dec.stdout[-3000:] + dec.stderr[-3000:]
+    iv = os.path.join(d, "emb", "alone")
+    from pytorch_kaldi_resnet_amd import kaldi_io, scoring
+    emb = scoring.read_embeddings(iv)
+    assert len(emb) == sum(1 for _ in open(os.path.join(d, "decode.scp")))
+    # the CPU oracle on the same checkpoint
+    from oracle import spk_oracle as O
+    st = {k: v.clone() for k, v in ckpt["state_dict"].items()}
+    o_emb = {}
+    with torch.no_grad():
+        for line in open(os.path.join(d, "decode.scp")):
+            utt, rx = line.split()
+            x = torch.from_numpy(np.ascontiguousarray(kaldi_io.read_mat(rx).T))[None]
+            o_emb[utt] = O.embed(st, x, "mean+std", "resnet34", train=False)[0].numpy().astype(np.float64)
+    worst = 0.0
+    for utt, v in emb.items():
+        a, b = np.asarray(v), o_emb[utt]
+        worst = max(worst, 1 - float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))))
+    print("max 1-cos HIP vs oracle over %d utts: %.3e" % (len(emb), worst))
+    assert worst < 1e-4
+    # scoring scripts
+    trials = os.path.join(d, "trials")
+    utts = sorted(emb)
+    with open(trials, "w") as f:
+        for i, a in enumerate(utts):
+            for b in utts[i + 1:]:
+                f.write("%s %s %s\n" % (a, b, "target" if a[:5] == b[:5] else "nontarget"))
+    for cmd in (["compute_mean.py", iv, os.path.join(d, "mean.vec")],
+                ["cosine_score.py", "--mean", os.path.join(d, "mean.vec"), "--enroll", iv, "--test", iv, "--trials", trials,
+                 "--score-file", os.path.join(d, "scores")]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", cmd[0])] + cmd[1:], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "compute_eer.py"), os.path.join(d, "scores"), trials],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("%")
+    mean_o = np.mean(np.stack([o_emb[u] for u in utts]).astype(np.float32), axis=0)
+    sc_o, lab = scoring.cosine_score(o_emb, o_emb, trials, mean_o)
+    eer_o = scoring.compute_eer(sc_o, lab)
+    eer_h = float(r.stdout.strip().rstrip("%")) / 100
+    print("EER hip %.4f oracle %.4f" % (eer_h, eer_o))
+    assert abs(eer_h - eer_o) <= 0.005 + 1e-9
