@@ -96,6 +96,10 @@ class Engine:
         self.pool_mode = 1 if model.pooling == "mean+std" else 0
         self.dirty = True
         self._packed_for_bwd = False
+        # weight gradients (compute-bound, off the critical path) run on a side stream so that they overlap the
+        # HBM-bound BatchNorm-backward passes of the main dgrad chain
+        self.wgrad_stream = None
+        self.use_side_stream = True
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def _all_convs(self):
@@ -267,6 +271,24 @@ class Engine:
                 logits, _ = self._head_fwd(emb, y, False, False)
             return logits
 
+    # ---- side-stream weight gradients ----------------------------------------------------------------------------
+    def _wgrad(self, x, dy, dw, k, stride, in_affine=None, accumulate=False):
+        if not self.use_side_stream:
+            return ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate)
+        if self.wgrad_stream is None:
+            self.wgrad_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        side = self.wgrad_stream
+        side.wait_stream(main)                      # dy / x are produced on the main stream
+        for t in (x, dy):
+            t.record_stream(side)                   # keep the allocator from recycling them under the side kernel
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate)
+
+    def _join_wgrad(self):
+        if self.use_side_stream and self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
     # ---- backward ---------------------------------------------------------------------------------------------
     def backward(self, saved, dlogits, on_stage_done=None):
         """Hand-written backward of forward_train.  Parameter gradients go to the .grad arena views (overwritten
@@ -289,12 +311,14 @@ class Engine:
                 d = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc)
                 saved["blocks"][bi] = None
                 if on_stage_done and (bi == 0 or stage_of[bi - 1] != stage_of[bi]):
+                    self._join_wgrad()
                     on_stage_done("layer%d" % stage_of[bi])
             # stem: d is the gradient wrt relu(bn(raw0))
             bn = self.stem_bn
             draw0 = ops.bn_backward(d, saved["raw0"], None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad,
                                     MASK_RAW, draw_out=d, accumulate=acc)
             ops.stem_wgrad(saved["x"], draw0, self.stem_conv.h.weight.grad, accumulate=acc)
+            self._join_wgrad()
             if on_stage_done:
                 on_stage_done("stem")
 
@@ -309,13 +333,13 @@ class Engine:
         for i in range(n - 1, 0, -1):
             c, pbn = b.convs[i], b.bns[i - 1]
             # conv i consumed relu(bn_{i-1}(raw_{i-1})) through its fused input transform
-            ops.conv_wgrad(raws[i - 1], draw, c.h.weight.grad, c.k, c.stride, in_affine=(pbn.t4[2], pbn.t4[3]),
-                           accumulate=acc)
+            self._wgrad(raws[i - 1], draw, c.h.weight.grad, c.k, c.stride, in_affine=(pbn.t4[2], pbn.t4[3]),
+                        accumulate=acc)
             da = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (raws[i - 1].shape[1], raws[i - 1].shape[2]))
             draw = ops.bn_backward(da, raws[i - 1], None, pbn.t4, pbn.h.weight.data, pbn.h.weight.grad, pbn.h.bias.grad,
                                    MASK_RAW, draw_out=da, accumulate=acc)
         c = b.convs[0]
-        ops.conv_wgrad(x, draw, c.h.weight.grad, c.k, c.stride, accumulate=acc)
+        self._wgrad(x, draw, c.h.weight.grad, c.k, c.stride, accumulate=acc)
         if b.ds is None:
             dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]), add=dz)
         else:
@@ -323,7 +347,7 @@ class Engine:
             cd, bnd = b.ds
             drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
                                     MASK_NONE, draw_out=dz, accumulate=acc)
-            ops.conv_wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
+            self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
             ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True)
         return dx
 

@@ -142,7 +142,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = str(device)
+    """Scratch buffer per (device, launch stream): kernels on different streams never share one."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
