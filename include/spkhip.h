@@ -45,7 +45,7 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
  * (oy*IS + tap_dy[t], ox*IS + tap_dx[t]) with weight tap tap_w[t] and is stored at (oy*OS + ooy, ox*OS + oox)
  * of the physical [B][OHf][OWf][Cout] output.  TH x TW = pixel region per block (<= 128*MT pixels),
  * MT in 1..4 m-tiles per wave, NT in {1,2,4} 32-channel n-tiles per block.
- * stats (EPI_STATS): [B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats. */
+ * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,

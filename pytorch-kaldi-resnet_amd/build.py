@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o] + os.environ.get("SPK_CXXFLAGS", "").split()
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()

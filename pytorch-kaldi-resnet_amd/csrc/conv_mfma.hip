@@ -19,6 +19,9 @@
 #include "spk_common.h"
 
 #define CK 32
+#ifndef STAGE_U
+#define STAGE_U 4   // staging loads in flight per thread
+#endif
 #define LPS 36  // LDS floats per staged pixel: 32 + 4 pad -> conflict-free ds_read_b128
 
 struct ConvArgs {
@@ -49,6 +52,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+#ifdef PRIO_STAGGER
+    // Two blocks share a CU (one wave each per SIMD) and run the same program: at equal priority they advance in
+    // lockstep and reach their staging/barrier phases together, leaving the matrix pipe idle.  A static priority
+    // for every other dispatch round breaks the symmetry: the favoured wave keeps the pipe, the other fills its gaps.
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
     // order (same pixel region, next cout group; then the neighbouring region) share an XCD's L2.
@@ -97,6 +106,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int quad = tid & 7;
 
     for (int ch = 0; ch < nchunks; ++ch) {
+        // K loop over (tap, 8-cin group), software-pipelined one group ahead: while the 4*MT*NT MFMAs of a group
+        // issue (>= 1 k cycles), the B fragments (L2 -> VGPR) and A fragments (LDS -> VGPR) of the next group are
+        // already in flight, and the next tap's table entries (scalar loads) are fetched a whole tap early, so the
+        // matrix pipe never waits on a memory round trip inside a wave.
+        const f32x4* lds4 = (const f32x4*)lds;
+        const float* wbase = a.wpk + ((size_t)(ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
+        const size_t tap_stride = (size_t)(a.Cin >> 3) * cout32 * 256;
+        const size_t grp_stride = (size_t)cout32 * 256;
+        auto load_b = [&](f32x4* bf, int tw, int g) {
+            const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
+#ifdef ABL_NO_BLOAD
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bf[j]) : "s"(wp));
+#else
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + j * 256);
+#endif
+        };
+        auto load_a = [&](f32x4* af, int toff4, int g) {
+#ifdef ABL_NO_ALOAD
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(af[i]) : "s"(toff4 + g));
+#else
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = lds4[lbase[i] + toff4 + g * 2];
+#endif
+        };
+        auto mma = [&](const f32x4* af, const f32x4* bf) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        };
+        // B fragments are prefetched a whole tap (4 groups >= 4 k MFMA cycles) ahead into a 4-deep register ring;
+        // A fragments one group ahead (LDS latency is ~100 cycles).
+        f32x4 bq[4][NT], a0[MT], a1[MT];
+#if defined(ABL_NO_BLOAD) || defined(ABL_NO_ALOAD)
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < NT; ++j) bq[g][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
+        for (int i = 0; i < MT; ++i) a0[i] = a1[i] = (f32x4){1.f, 2.f, 3.f, 4.f};
+#endif
+        int tw = a.tap_w[0], toff = a.tap_off[0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_b(bq[g], tw, g);
         __syncthreads();  // every wave is done reading the previous chunk's tile
         {
             const int c = ch * CK + quad * 4;
@@ -107,8 +163,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
             // U independent 16-byte loads in flight per thread (addresses clamped, zero selected afterwards: no branch
             // around a load, so the compiler issues the whole batch before the first wait)
-            constexpr int U = 4;
+            constexpr int U = STAGE_U;
+#ifdef ABL_NO_STAGE
+            for (int base = tid >> 3; base < 0; base += 32 * U) {
+#else
             for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
+#endif
                 f32x4 v[U];
                 bool inb[U];
 #pragma unroll
@@ -140,126 +200,108 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
         __syncthreads();
 
-        // K loop over (tap, 8-cin group), software-pipelined one group ahead: while the 4*MT*NT MFMAs of a group
-        // issue (>= 1 k cycles), the B fragments (L2 -> VGPR) and A fragments (LDS -> VGPR) of the next group are
-        // already in flight, and the next tap's table entries (scalar loads) are fetched a whole tap early, so the
-        // matrix pipe never waits on a memory round trip inside a wave.
-        const f32x4* lds4 = (const f32x4*)lds;
-        const float* wbase = a.wpk + ((size_t)(ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
-        const size_t tap_stride = (size_t)(a.Cin >> 3) * cout32 * 256;
-        const size_t grp_stride = (size_t)cout32 * 256;
-        auto load_b = [&](f32x4* bf, int tw, int g) {
-            const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + j * 256);
-        };
-        auto load_a = [&](f32x4* af, int toff4, int g) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = lds4[lbase[i] + toff4 + g * 2];
-        };
-        auto mma = [&](const f32x4* af, const f32x4* bf) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        };
-        f32x4 b0[NT], b1[NT], a0[MT], a1[MT];
-        int tw = a.tap_w[0], toff = a.tap_off[0];
-        load_b(b0, tw, 0);
         load_a(a0, toff, 0);
         for (int t = 0; t < a.ntaps; ++t) {
             const bool more = t + 1 < a.ntaps;
             const int tn = more ? t + 1 : t;
             const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn];
-            load_b(b1, tw, 1);
+            // group 0
             load_a(a1, toff, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
+            mma(a0, bq[0]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(b0, tw, 2);
+            if (more) load_b(bq[0], tw_n, 0);
+            // group 1
             load_a(a0, toff, 2);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
+            mma(a1, bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(b1, tw, 3);
+            if (more) load_b(bq[1], tw_n, 1);
+            // group 2
             load_a(a1, toff, 3);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
+            mma(a0, bq[2]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                load_b(b0, tw_n, 0);
-                load_a(a0, toff_n, 0);
-            }
+            if (more) load_b(bq[2], tw_n, 2);
+            // group 3
+            if (more) load_a(a0, toff_n, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
+            mma(a1, bq[3]);
             __builtin_amdgcn_sched_barrier(0);
+            if (more) load_b(bq[3], tw_n, 3);
             tw = tw_n;
             toff = toff_n;
         }
     }
 
-    // ---- epilogue: C/D layout of the 32x32 tile is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float es[NT], eh[NT], ssum[NT], ssq[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        es[j] = 1.f;
-        eh[j] = 0.f;
-        ssum[j] = 0.f;
-        ssq[j] = 0.f;
-        if (flags & SPK_EPI_AFFINE) {
-            es[j] = a.epi_scale[n0 + j * 32 + r];
-            eh[j] = a.epi_shift[n0 + j * 32 + r];
-        }
+    // ---- epilogue.  C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane
+    // holds ONE channel of 16 pixels.  Each wave transposes one m-tile at a time through a private LDS slab
+    // [32 pixels][NT*32 + 4] so that a lane then owns 4 consecutive channels of one pixel: 16-byte global stores,
+    // 16-byte residual / scale loads, and 4x fewer store instructions.  No block barrier after the first one:
+    // statistics are reduced per wave (shuffles) and written as one partial row per wave.
+    constexpr int LW = NT * 32 + 4;        // slab row pitch in floats (16-byte aligned, bank-staggered)
+    constexpr int Q = NT * 8;              // float4 quads per pixel row
+    constexpr int RPP = 64 / Q;            // pixel rows covered by one 64-lane pass
+    __syncthreads();                       // all waves are done with the input tile
+    float* slab = lds + wave * (32 * LW);
+    const int qc = lane % Q;               // this lane's channel quad
+    const int qr = lane / Q;               // and its row within a pass
+    f32x4 es = {1.f, 1.f, 1.f, 1.f}, eh = {0.f, 0.f, 0.f, 0.f};
+    if (flags & SPK_EPI_AFFINE) {
+        es = *(const f32x4*)(a.epi_scale + n0 + qc * 4);
+        eh = *(const f32x4*)(a.epi_shift + n0 + qc * 4);
     }
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int ob = __shfl(obase[i], row, 64);
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                float v = acc[i][j][e];
-                if (ob >= 0) {
-                    const int addr = ob + j * 32 + r;
-                    if (flags & SPK_EPI_AFFINE) v = v * es[j] + eh[j];
-                    if (flags & SPK_EPI_ADD) v += a.epi_add[addr];
-                    if (flags & SPK_EPI_RELU) v = fmaxf(v, 0.f);
-                    a.out[addr] = v;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[row * LW + j * 32 + r] = acc[i][j][e];
+            }
+        // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
+#pragma unroll
+        for (int k = 0; k < 32 / RPP; ++k) {
+            const int row = k * RPP + qr;
+            const int ob = __shfl(obase[i], row, 64);
+            f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
+#ifdef ABL_NO_EPI
+            asm volatile("" ::"v"(v));
+            if (ob == -12345) {
+#else
+            if (ob >= 0) {
+#endif
+                float* dst = a.out + ob + qc * 4;
+                if (flags & SPK_EPI_AFFINE) v = v * es + eh;
+                if (flags & SPK_EPI_ADD) v += *(const f32x4*)(a.epi_add + ob + qc * 4);
+                if (flags & SPK_EPI_RELU) {
+                    v[0] = fmaxf(v[0], 0.f);
+                    v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f);
+                    v[3] = fmaxf(v[3], 0.f);
                 }
+                *(f32x4*)dst = v;
+                ssum += v;
+                ssq += v * v;
             }
         }
     }
     if (flags & SPK_EPI_STATS) {
+        // lanes with equal qc hold the same 4 channels: fold them (lane strides Q, 2Q, ... < 64)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 32, 64);
-            ssq[j] += __shfl_xor(ssq[j], 32, 64);
-        }
-        __syncthreads();  // LDS tile no longer needed
-        if (h == 0) {
+        for (int off = Q; off < 64; off <<= 1) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                lds[((wave * NT + j) * 32 + r) * 2 + 0] = ssum[j];
-                lds[((wave * NT + j) * 32 + r) * 2 + 1] = ssq[j];
+            for (int c = 0; c < 4; ++c) {
+                ssum[c] += __shfl_xor(ssum[c], off, 64);
+                ssq[c] += __shfl_xor(ssq[c], off, 64);
             }
         }
-        __syncthreads();
-        if (tid < NT * 32) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                s0 += lds[((w * NT) * 32 + tid) * 2 + 0];
-                s1 += lds[((w * NT) * 32 + tid) * 2 + 1];
-            }
-            float* dst = a.stats + ((size_t)ptile * a.Cout + n0 + tid) * 2;
-            dst[0] = s0;
-            dst[1] = s1;
+        if (lane < Q) {
+            float* dst = a.stats + ((size_t)(ptile * 4 + wave) * a.Cout + n0 + lane * 4) * 2;
+            *(f32x4*)dst = (f32x4){ssum[0], ssq[0], ssum[1], ssq[1]};
+            *(f32x4*)(dst + 4) = (f32x4){ssum[2], ssq[2], ssum[3], ssq[3]};
         }
     }
 }
@@ -316,7 +358,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.nblocks = B * a.tiles_y * a.tiles_x * a.ncg;
     a.flags = flags;
     size_t lds_bytes = (size_t)a.halo_h * a.halo_w * LPS * sizeof(float);
-    const size_t red_bytes = (size_t)4 * NT * 32 * 2 * sizeof(float);
+    const size_t red_bytes = (size_t)4 * 32 * (NT * 32 + 4) * sizeof(float);   // epilogue transpose slabs, one per wave
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);
     hipStream_t st = (hipStream_t)stream;

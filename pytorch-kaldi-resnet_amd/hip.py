@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspkhip.so")
+LIB_PATH = os.environ.get("SPK_LIB", os.path.join(_HERE, "libspkhip.so"))   # SPK_LIB: A/B builds of the same ABI
 
 IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS = 1, 2, 4, 8, 16
 MASK_NONE, MASK_ACT, MASK_RAW = 0, 1, 2

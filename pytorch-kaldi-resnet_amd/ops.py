@@ -66,7 +66,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     stats = None
     if want_stats:
         flags |= EPI_STATS
-        ntile = B * (-(-OH // TH)) * (-(-OW // TW))
+        ntile = 4 * B * (-(-OH // TH)) * (-(-OW // TW))      # one partial row per wave
         stats = torch.empty(ntile, Cout, 2, device=x.device, dtype=torch.float32)
     call("spk_conv_mfma", ptr(x), ptr(wpk), ptr(out),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
