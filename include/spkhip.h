@@ -55,7 +55,9 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
 /* Weight gradient of a 3x3 (pad 1) or 1x1 (pad 0) conv at stride 1 or 2 (autograd of nn.Conv2d).
  * x: conv input [B][IH][IW][Cin] (optionally raw + fused BN/ReLU via in_scale/in_shift and SPK_IN_AFFINE_RELU),
  * dy: gradient of the raw conv output [B][OH][OW][Cout]; dw: OIHW [Cout][Cin][k][k].
- * partial: workspace of spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout) bytes. TW must be even. */
+ * partial: workspace of spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout) bytes. TW must be even; the region must fit
+ * the kernel's register prefetch window: halo pixels <= *max_halo_pix, TH*TW <= *max_tile_pix (spk_conv_wgrad_limits). */
+int spk_conv_wgrad_limits(int WN, int* max_halo_pix /*host*/, int* max_tile_pix /*host*/);
 size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
 int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                    const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,

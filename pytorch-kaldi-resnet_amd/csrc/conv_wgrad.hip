@@ -11,6 +11,13 @@
 // order (deterministic) and writes OIHW.
 #include "spk_common.h"
 
+#ifndef WGRAD_NX
+#define WGRAD_NX 5   // prefetch registers (float4) per thread for the X halo tile: halo_pix <= 32*NX
+#endif
+#ifndef WGRAD_ND
+#define WGRAD_ND 4   // and for the dY tile: npix <= (256/(8*WN))*ND
+#endif
+
 struct WgradArgs {
     const float* x;
     const float* dy;
@@ -61,7 +68,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int half_w = a.TW >> 1;
     const int ksteps = a.TH * half_w;
 
-    for (int region = blockIdx.x; region < a.nregions; region += a.nsplit) {
+    // Region pipeline ("issue early / write late"): the global loads of region i+1 are issued into registers right
+    // after the barrier that publishes region i's LDS tiles, fly during region i's MFMAs, and are written to LDS
+    // (with the fused BN+ReLU) after the barrier that ends region i.  The host caps the tiles so that NX + ND
+    // 16-byte registers per thread hold one region (spk_conv_wgrad: halo_pix <= 32*NX, npix <= PSTEP*ND).
+    constexpr int NX = WGRAD_NX;                 // X halo float4 per thread
+    constexpr int ND = WGRAD_ND;                 // dY float4 per thread
+    constexpr int QPP = WN * 8;                  // dY float4 quads per pixel
+    constexpr int PSTEP = 256 / QPP;             // dY pixels per pass
+    const int cq = tid % QPP;
+    f32x4 px[NX], pd[ND];
+    unsigned inx = 0, ind = 0;                   // in-image bit masks of the prefetched slots
+
+    auto prefetch = [&](int region) {
         int pt = region;
         const int tx = pt % a.tiles_x;
         pt /= a.tiles_x;
@@ -69,67 +88,69 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         const int b = pt / a.tiles_y;
         const int oy0 = ty * a.TH, ox0 = tx * a.TW;
         const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
-        __syncthreads();  // previous region fully consumed
-        {   // X halo tile, 32 channels, optional fused BN+ReLU of the producing layer; U loads in flight per thread
-            constexpr int U = 4;
-            for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
-                f32x4 v[U];
-                bool inb[U];
+        inx = 0;
+        ind = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int p = base + 32 * u;
-                    p = p < halo_pix ? p : halo_pix - 1;
-                    const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
-                    const int hx = p - hy * a.halo_w;
-                    const int iy = iy0 + hy, ix = ix0 + hx;
-                    inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-                    const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                    v[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int p = base + 32 * u;
-                    f32x4 w = v[u];
-                    if (flags & SPK_IN_AFFINE_RELU) {
-                        w = w * sc + sh;
-                        w[0] = fmaxf(w[0], 0.f);
-                        w[1] = fmaxf(w[1], 0.f);
-                        w[2] = fmaxf(w[2], 0.f);
-                        w[3] = fmaxf(w[3], 0.f);
-                    }
-                    if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (p < halo_pix) *(f32x4*)(xs + p * 32 + quad * 4) = w;
-                }
-            }
+        for (int u = 0; u < NX; ++u) {
+            int p = (tid >> 3) + 32 * u;
+            p = p < halo_pix ? p : halo_pix - 1;
+            const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+            const int hx = p - hy * a.halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) inx |= 1u << u;
+            const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+#ifndef ABL_NO_STAGE
+            px[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
+#endif
         }
-        {   // dY tile: zero outside the image, so border pixels contribute nothing
-            constexpr int QPP = WN * 8;         // float4 quads per pixel
-            constexpr int PSTEP = 256 / QPP;    // pixels per pass
-            constexpr int U = 4;
-            const int cq = tid % QPP;
-            for (int base = tid / QPP; base < npix; base += PSTEP * U) {
-                f32x4 v[U];
-                bool inb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int p = base + PSTEP * u;
-                    p = p < npix ? p : npix - 1;
-                    const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
-                    const int lx = p - ly * a.TW;
-                    const int oy = oy0 + ly, ox = ox0 + lx;
-                    inb[u] = oy < a.OH && ox < a.OW;
-                    const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
-                    v[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int p = base + PSTEP * u;
-                    f32x4 w = inb[u] ? v[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (p < npix) *(f32x4*)(dys + p * (WN * 32) + cq * 4) = w;
-                }
-            }
+        for (int u = 0; u < ND; ++u) {
+            int p = tid / QPP + PSTEP * u;
+            p = p < npix ? p : npix - 1;
+            const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+            const int lx = p - ly * a.TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            if (oy < a.OH && ox < a.OW) ind |= 1u << u;
+            const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
+#ifndef ABL_NO_STAGE
+            pd[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+#endif
         }
+    };
+    auto publish = [&]() {      // registers -> LDS (zero outside the image; BN+ReLU of the producing layer fused)
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int p = (tid >> 3) + 32 * u;
+            f32x4 w = px[u];
+            if (flags & SPK_IN_AFFINE_RELU) {
+                w = w * sc + sh;
+                w[0] = fmaxf(w[0], 0.f);
+                w[1] = fmaxf(w[1], 0.f);
+                w[2] = fmaxf(w[2], 0.f);
+                w[3] = fmaxf(w[3], 0.f);
+            }
+            if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < halo_pix) *(f32x4*)(xs + p * 32 + quad * 4) = w;
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int p = tid / QPP + PSTEP * u;
+            const f32x4 w = ((ind >> u) & 1) ? pd[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < npix) *(f32x4*)(dys + p * (WN * 32) + cq * 4) = w;
+        }
+    };
+#ifdef ABL_NO_STAGE
+    for (int u = 0; u < NX; ++u) px[u] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    for (int u = 0; u < ND; ++u) pd[u] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#endif
+
+    int region = blockIdx.x;
+    if (region < a.nregions) prefetch(region);
+    for (; region < a.nregions; region += a.nsplit) {
+        __syncthreads();   // previous region fully consumed
+        publish();
         __syncthreads();
+        if (region + a.nsplit < a.nregions) prefetch(region + a.nsplit);
 
         // k-steps of this wave: kk = wk, wk + WK, ...; operands of step i+1 are read from LDS while the NTAPS MFMAs
         // of step i issue (ping-pong register sets), so the matrix pipe does not wait on LDS latency.
@@ -137,6 +158,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         int qy = wk / half_w, j = wk - qy * half_w;   // position of the next step to load
         auto load_step = [&](float& bval, float* av) {
             const int qx = 2 * j + h;
+#ifdef ABL_NO_LDSREAD
+            asm volatile("" : "+v"(bval) : "s"(qy));
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) asm volatile("" : "+v"(av[t]) : "s"(j));
+#else
             bval = dys[(qy * a.TW + qx) * (WN * 32) + wn * 32 + r];
             const int xb = ((qy * a.S) * a.halo_w + qx * a.S) * 32 + r;
             // taps of one kernel row are 32 floats apart: the compiler pairs them into ds_read2_b32
@@ -144,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < KS; ++kw) av[kh * KS + kw] = xs[xb + kh * row_stride + kw * 32];
+#endif
             j += WK;
             while (j >= half_w) {
                 j -= half_w;
@@ -155,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             for (int t = 0; t < NTAPS; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bval, acc[t], 0, 0, 0);
         };
-        float bv0, bv1, av0[NTAPS], av1[NTAPS];
+        float bv0 = 1.f, bv1 = 1.f, av0[NTAPS], av1[NTAPS];
+#ifdef ABL_NO_LDSREAD
+        for (int t = 0; t < NTAPS; ++t) av0[t] = av1[t] = 1.f;
+#endif
         if (nsteps > 0) load_step(bv0, av0);
         for (int i = 0; i < nsteps; i += 2) {
             const bool has1 = i + 1 < nsteps;
@@ -234,6 +264,13 @@ static int launch_wgrad(const WgradArgs& a, size_t lds_bytes, hipStream_t st) {
     return 0;
 }
 
+extern "C" int spk_conv_wgrad_limits(int WN, int* max_halo_pix, int* max_tile_pix) {
+    if (WN != 1 && WN != 2 && WN != 4) return -1;
+    *max_halo_pix = 32 * WGRAD_NX;
+    *max_tile_pix = (256 / (8 * WN)) * WGRAD_ND;
+    return 0;
+}
+
 extern "C" size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout) {
     return (size_t)nsplit * ksize * ksize * Cin * Cout * sizeof(float);
 }
@@ -270,6 +307,10 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     const size_t red_bytes = (WK > 1) ? (size_t)WN * ntaps * 16 * 64 * sizeof(float) : 0;
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad: tile %dx%d needs %zu B of LDS", TH, TW, lds_bytes);
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",
+                a.halo_h, a.halo_w, 32 * WGRAD_NX);
+    SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
+                TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
     hipStream_t st = (hipStream_t)stream;
     int rc = -1;
     if (ntaps == 9) {

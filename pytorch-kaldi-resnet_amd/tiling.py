@@ -78,21 +78,28 @@ def _conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
     return best[1]
 
 
+# prefetch-window limits of conv_wgrad_kernel (csrc/conv_wgrad.hip: WGRAD_NX = 5, WGRAD_ND = 4; also exported as
+# spk_conv_wgrad_limits): the next region must fit in 9 float4 registers per thread
+WGRAD_MAX_HALO = 32 * 5
+WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
+
+
 @lru_cache(maxsize=None)
 def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
-    """-> (TH, TW, WN).  TW even; LDS = X halo (128 B/pixel) + dY tile (WN*128 B/pixel) <= 72 KiB."""
+    """-> (TH, TW, WN).  TW even; halo <= WGRAD_MAX_HALO pixels, tile <= WGRAD_MAX_TILE[WN] pixels."""
     WN = 1 if Cout == 32 else 2
     best = None
     OWe = OW + (OW & 1)
     for TH in range(1, OH + 1):
         for TW in range(2, OWe + 1, 2):
+            if TH * TW > WGRAD_MAX_TILE[WN]:
+                break
             halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
-            lds = halo * 128 + TH * TW * WN * 128
-            if lds > 72 * 1024:
+            if halo > WGRAD_MAX_HALO:
                 continue
             ty, tx = -(-OH // TH), -(-OW // TW)
-            # MFMA work ~ padded pixels; staging ~ halo + tile; small tiles pay more barriers
-            cost = ty * tx * (TH * TW * 9.0 * (ksize * ksize) / 9.0 * 32 + halo * 8.0 + TH * TW * WN * 8.0 + 600.0)
+            # MFMA work ~ padded pixels; every region also pays two barriers and a pipeline fill (~24 pixel-equivalents)
+            cost = ty * tx * (TH * TW + 24.0 + 0.1 * halo)
             key = (cost, -TH * TW)
             if best is None or key < best[0]:
                 best = (key, (TH, TW, WN))
@@ -100,9 +107,12 @@ def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
     return best[1]
 
 
-def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=768):
+WGRAD_TARGET_BLOCKS = 512      # persistent wgrad blocks per launch = 2 per CU x 256 CUs (measured best of 512/768/1024)
+
+
+def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=None):
     per = (Cin // 32) * (Cout // (32 * WN))
-    return max(1, min(nregions, target_blocks // per))
+    return max(1, min(nregions, (target_blocks or WGRAD_TARGET_BLOCKS) // per))
 
 
 _load_table()

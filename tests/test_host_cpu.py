@@ -203,4 +203,8 @@ def test_tile_selection_invariants(shape):
     for k, s in [(3, 1), (3, 2), (1, 2), (1, 1)]:
         TH, TW, WN = tiling.wgrad_tile(OH, OW, 64, 64, k, s)
         assert TW % 2 == 0 and WN in (1, 2, 4)
-        assert (((TH - 1) * s + k) * ((TW - 1) * s + k) + TH * TW * WN) * 128 <= 160 * 1024
+        import ctypes
+        mh, mt = ctypes.c_int(), ctypes.c_int()
+        assert hip.lib().spk_conv_wgrad_limits(WN, ctypes.byref(mh), ctypes.byref(mt)) == 0
+        assert ((TH - 1) * s + k) * ((TW - 1) * s + k) <= mh.value == tiling.WGRAD_MAX_HALO
+        assert TH * TW <= mt.value == tiling.WGRAD_MAX_TILE[WN]

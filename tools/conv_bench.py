@@ -22,9 +22,12 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--feat", type=int, default=80)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--wgrad-blocks", type=int, default=0)
 ap.add_argument("--out", default=os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "tile_table.json"))
 args = ap.parse_args()
 B, F, T = args.batch, args.feat, args.frames
+if args.wgrad_blocks:
+    tiling.WGRAD_TARGET_BLOCKS = args.wgrad_blocks
 dev = "cuda"
 
 
@@ -110,6 +113,31 @@ for name, Cin, Cout, H, W, k, s in shapes:
         if s == 1 and k == 3:
             # the stride-1 data gradient is the same launch shape with Cin/Cout swapped (equal here)
             pass
+    if args.sweep:
+        wkey = (OH, OW, Cin, Cout, k, s)
+        res = []
+        OWe = OW + (OW & 1)
+        for WN in ((1,) if Cout == 32 else (1, 2)):
+            cands = []
+            for TH in range(1, OH + 1):
+                for TW in range(2, OWe + 1, 2):
+                    if TH * TW > tiling.WGRAD_MAX_TILE[WN] or ((TH - 1) * s + k) * ((TW - 1) * s + k) > tiling.WGRAD_MAX_HALO:
+                        continue
+                    ty, tx = -(-OH // TH), -(-OW // TW)
+                    cands.append((ty * tx * (TH * TW + 24.0), TH, TW))
+            cands.sort()
+            for _, TH, TW in cands[:8]:
+                tiling.FORCE_WGRAD[wkey] = (TH, TW, WN)
+                try:
+                    ms = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
+                except RuntimeError:
+                    continue
+                res.append((ms, (TH, TW, WN)))
+        res.sort()
+        tiling.FORCE_WGRAD[wkey] = res[0][1]
+        table["wgrad"][",".join(map(str, wkey))] = list(res[0][1])
+        print("%-12s wgrad best %s %.3f ms %.1f TF | top: %s" % (name, res[0][1], res[0][0], flops / res[0][0] / 1e9,
+              " ".join("%s:%.3f" % (c, m) for m, c in res[:5])), flush=True)
     t_fwd = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
     t_dg = timeit(lambda: ops.conv_dgrad(dy, wpk_t, Cin, k, s, (H, W), out=dx), args.reps)
     t_wg = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
