@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="per-GPU batch (256 = the BASELINE config)")
     ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--mode", choices=["train", "predict"], default="train",
+                    help="train = the BASELINE metric (default); predict = eval-mode embedding extraction (decode.py path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -113,13 +115,23 @@ def main():
     y = torch.randint(0, SPK, (args.batch,), device=dev, generator=gen)
     eng = model.engine()
 
-    def step():
+    if args.mode == "predict":
+        model.eval()
+
+        def step():
+            return model.predict(x).sum()
+    else:
+        step = None
+
+    def train_step():
         opt.zero_grad(set_to_none=True)
         loss, _, _ = eng.loss_and_grad(x, y, red.on_stage_done if world > 1 else None)
         red.finish()
         opt.step()
         return loss
 
+    if step is None:
+        step = train_step
     log("model built, starting warm-up")
     for i in range(args.warmup):
         step()
@@ -145,7 +157,7 @@ def main():
     log("timed region done: %.3f s for %d steps" % (dt, args.steps))
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.mode == "train":
         # instrumented pass: same steps, every launch bracketed by HIP events on its launch stream; the side stream
         # for weight gradients is folded into the main stream here so kernels do not overlap while being timed
         eng.use_side_stream = False
@@ -163,22 +175,31 @@ def main():
             a[2] += 1
         name, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fsum / tsum / 1e12
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            ent = json.load(open(pmc))["kernels"].get(name.replace(",", ", "))
+            if ent:
+                traffic = round(ent["hbm_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                     "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
                     "gflop_per_launch": round(fsum / n / 1e9, 3),
                     "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
                                         "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
                                         "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
         log("roofline pass done; timing the CPU oracle (bounded sample)")
         cpu = cpu_baseline(args)
         log("cpu baseline done")
     if rank == 0:
         gb = args.batch * world
         out = {
-            "metric": "utterances/sec (300-frame x 80 fbank, bs256/GPU), ResNet-34 + AAM-softmax training step",
+            "metric": "utterances/sec (300-frame x 80 fbank, bs256/GPU), ResNet-34 + AAM-softmax training step"
+            if args.mode == "train" else "utterances/sec, eval-mode embedding extraction (predict), ResNet-34",
             "value": round(gb * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -107,7 +107,8 @@ def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
     return best[1]
 
 
-WGRAD_TARGET_BLOCKS = 512      # persistent wgrad blocks per launch = 2 per CU x 256 CUs (measured best of 512/768/1024)
+import os as _os
+WGRAD_TARGET_BLOCKS = int(_os.environ.get('SPK_WGRAD_BLOCKS', '512'))      # persistent wgrad blocks per launch = 2 per CU x 256 CUs (measured best of 512/768/1024)
 
 
 def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=None):
