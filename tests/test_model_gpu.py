@@ -167,6 +167,34 @@ def test_fused_step_equals_autograd_path(P, gold_dir):
     assert float((m2.flat_grads() - 2 * g2c).norm() / g2c.norm()) < 1e-5
 
 
+def test_graphed_step_equals_eager(P, gold_dir):
+    """The hipGraph-captured forward+CE+backward must reproduce the eager launch sequence bit for bit (same kernels,
+    same order per stream), replay after replay, and keep BN running statistics advancing."""
+    from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
+    meta = json.load(open(os.path.join(gold_dir, "c1_r34_aam.json")))
+    x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m1, _ = build(P, meta)
+    m1.train()
+    l1, lg1, r1 = m1.engine().loss_and_grad(xg, yg)
+    g1 = m1.flat_grads().clone()
+    m2, _ = build(P, meta)
+    m2.train()
+    step = GraphedTrainStep(m2.engine(), meta["batch"], meta["frames"], warmup=1)
+    m2.load_state_dict(m1.state_dict())          # undo the warm-up's running-stat updates ... and compare from here
+    m1b, _ = build(P, meta)
+    m1b.load_state_dict(m1.state_dict())
+    m1b.train()
+    l1b, _, _ = m1b.engine().loss_and_grad(xg, yg)
+    l2, lg2, r2 = step(xg, yg)
+    assert float(l2) == float(l1b)
+    assert torch.equal(m2.flat_grads(), m1b.flat_grads())
+    assert torch.equal(m2.state_dict()["res.bn1.running_mean"], m1b.state_dict()["res.bn1.running_mean"])
+    l3, _, _ = step(xg, yg)                        # second replay: same batch statistics, same loss
+    assert float(l3) == float(l2)
+    assert int(m2.state_dict()["res.bn1.num_batches_tracked"]) == int(m1b.state_dict()["res.bn1.num_batches_tracked"]) + 1
+
+
 @pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40"])
 def test_sgd_loss_curve(P, gold_dir, name):
     from pytorch_kaldi_resnet_amd.optim import FlatSGD
