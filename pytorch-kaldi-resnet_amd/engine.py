@@ -383,7 +383,9 @@ class GraphedTrainStep:
         self.x = torch.zeros(batch, m.feat_dim, frames, device=dev)
         self.y = torch.zeros(batch, dtype=torch.long, device=dev)
         self.shape = (batch, m.feat_dim, frames)
-        # warm-up outside capture: allocates the workspaces / BN buffers the graph will reuse, picks tiles
+        # warm-up outside capture: allocates the workspaces / BN buffers the graph will reuse, picks tiles.
+        # It runs real steps on a dummy batch, so the BatchNorm running statistics are snapshotted and restored.
+        saved_buffers = [b.clone() for b in m.buffers()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -393,6 +395,8 @@ class GraphedTrainStep:
                 engine.loss_and_grad(self.x, self.y)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        for b, sb in zip(m.buffers(), saved_buffers):
+            b.copy_(sb)
         for p in m.parameters():
             p.grad = None                      # captured backward overwrites (no accumulation)
         self.graph = torch.cuda.CUDAGraph()

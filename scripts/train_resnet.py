@@ -60,6 +60,9 @@ parser.add_argument("--gpu", default=None, type=int)
 parser.add_argument("--gpu-num", default=-1, type=int)
 parser.add_argument("--multiprocessing-distributed", action="store_true")
 parser.add_argument("--max-steps", default=-1, type=int, help="stop each epoch after N steps (smoke runs)")
+parser.add_argument("--no-graph", action="store_true",
+                    help="launch kernels eagerly (stage-bucketed all-reduce overlapped with backward) instead of replaying "
+                         "the step as one hipGraph followed by one flat all-reduce")
 
 best_acc1 = 0
 
@@ -215,6 +218,7 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
     losses, top1, top5 = DeviceMeter("Loss", ":.4e"), DeviceMeter("Acc@1", ":6.2f"), DeviceMeter("Acc@5", ":6.2f")
     model.train()
     eng = model.engine()
+    graphed = getattr(eng, "_graphed_step", None)
     end = time.time()
     t_epoch, n_utt = time.time(), 0
     for i, (audios, target) in enumerate(loader):
@@ -223,9 +227,16 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
         dt_.update(time.time() - end)
         audios = audios.cuda(args.gpu, non_blocking=True)
         target = target.cuda(args.gpu, non_blocking=True).long()
-        optimizer.zero_grad(set_to_none=True)
-        loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if world > 1 else None)
-        reducer.finish()
+        if not args.no_graph and (graphed is None or not graphed.matches(audios)) and audios.size(0) == args.batch_size:
+            from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
+            graphed = eng._graphed_step = GraphedTrainStep(eng, audios.size(0), audios.size(2))
+        if not args.no_graph and graphed is not None and graphed.matches(audios):
+            loss, _, rank = graphed(audios, target)          # one hipGraph launch: fwd + CE + bwd
+            reducer.allreduce_all()
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if world > 1 else None)
+            reducer.finish()
         optimizer.step()
         n = audios.size(0)
         n_utt += n

@@ -180,8 +180,11 @@ def test_graphed_step_equals_eager(P, gold_dir):
     g1 = m1.flat_grads().clone()
     m2, _ = build(P, meta)
     m2.train()
+    before = {k: v.clone() for k, v in m2.state_dict().items()}
     step = GraphedTrainStep(m2.engine(), meta["batch"], meta["frames"], warmup=1)
-    m2.load_state_dict(m1.state_dict())          # undo the warm-up's running-stat updates ... and compare from here
+    for k, v in m2.state_dict().items():         # building the graph (dummy warm-up steps) must not touch the model
+        assert torch.equal(v, before[k]), k
+    m2.load_state_dict(m1.state_dict())
     m1b, _ = build(P, meta)
     m1b.load_state_dict(m1.state_dict())
     m1b.train()
