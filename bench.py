@@ -132,7 +132,12 @@ def main():
     graphed = None
     if args.mode == "train" and not args.no_graph:
         from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
-        graphed = GraphedTrainStep(eng, args.batch, args.frames)   # fwd + CE + bwd as one hipGraph
+        try:
+            graphed = GraphedTrainStep(eng, args.batch, args.frames)   # fwd + CE + bwd as one hipGraph
+        except Exception as e:     # keep the benchmark alive: same kernels, launched eagerly
+            log("hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e))
+            graphed = None
+            torch.cuda.synchronize()
 
     def train_step():
         if graphed is not None and PROFILE_OFF():

@@ -202,33 +202,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
         load_a(a0, toff, 0);
         for (int t = 0; t < a.ntaps; ++t) {
-            const bool more = t + 1 < a.ntaps;
-            const int tn = more ? t + 1 : t;
+            // the prefetches below are unconditional (the last tap re-fetches itself) so that the loop body is
+            // branch-free and the compiler can emit counted vmcnt waits instead of vmcnt(0) at every tap
+            const int tn = t + 1 < a.ntaps ? t + 1 : t;
             const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn];
             // group 0
             load_a(a1, toff, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, bq[0]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b(bq[0], tw_n, 0);
+            load_b(bq[0], tw_n, 0);
             // group 1
             load_a(a0, toff, 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b(bq[1], tw_n, 1);
+            load_b(bq[1], tw_n, 1);
             // group 2
             load_a(a1, toff, 3);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, bq[2]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b(bq[2], tw_n, 2);
+            load_b(bq[2], tw_n, 2);
             // group 3
-            if (more) load_a(a0, toff_n, 0);
+            load_a(a0, toff_n, 0);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, bq[3]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b(bq[3], tw_n, 3);
+            load_b(bq[3], tw_n, 3);
             tw = tw_n;
             toff = toff_n;
         }

@@ -400,7 +400,8 @@ class GraphedTrainStep:
         for p in m.parameters():
             p.grad = None                      # captured backward overwrites (no accumulation)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: helper threads of other libraries (the RCCL watchdog) may touch the device during capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.logits, self.rank = engine.loss_and_grad(self.x, self.y)
         engine.use_side_stream = side
 
