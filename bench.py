@@ -89,12 +89,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    # rehearsal hooks (one-GPU box): SPK_FORCE_DEVICE pins every rank to one device, SPK_DIST_BACKEND=gloo replaces
+    # RCCL so the N > 1 control flow can be exercised where only one GPU exists.  Never set by the driver.
+    if "SPK_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SPK_FORCE_DEVICE"])
+    backend = os.environ.get("SPK_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pytorch_kaldi_resnet_amd  # noqa: F401
     from pytorch_kaldi_resnet_amd import ops
@@ -188,7 +196,10 @@ def main():
         eng.use_side_stream = False
         ops.PROFILE = []
         for _ in range(2):
-            step()
+            # rank-local: no collective may be issued here, the other ranks are not in this pass
+            opt.zero_grad(set_to_none=True)
+            eng.loss_and_grad(x, y, None)
+            opt.step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         eng.use_side_stream = True
