@@ -31,7 +31,10 @@ const char* spk_last_error(void);
 #define SPK_EPI_AFFINE 2     /* out = acc*epi_scale[c] + epi_shift[c]   (eval-mode BN folded into the conv) */
 #define SPK_EPI_ADD 4        /* out += epi_add[same index]              (residual add / gradient accumulation) */
 #define SPK_EPI_RELU 8       /* out = max(out, 0) */
-#define SPK_EPI_STATS 16     /* stats[pixel_tile][c] = (sum, sumsq) of the stored values (train-mode BN) */
+#define SPK_EPI_STATS 16     /* stats[4*pixel_tile + wave][c] = (sum, sumsq) of the stored values (train-mode BN) */
+#define SPK_EPI_BNBWD 32     /* with EPI_STATS, data-gradient launches: stats = (sum dz, sum dz*xhat) of the BatchNorm whose
+                                output gradient this launch produces (dz = out * mask; mask = bn_act > 0, or
+                                bn_raw*scale+shift > 0 when bn_act is NULL; bn4 = [mean, invstd, scale, shift][Cout]) */
 
 /* ---- convolutions --------------------------------------------------------------------------------- */
 
@@ -47,7 +50,8 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
  * MT in 1..4 m-tiles per wave, NT in {1,2,4} 32-channel n-tiles per block.
  * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
-                  const float* epi_scale, const float* epi_shift, const float* epi_add, float* stats, int B, int IH,
+                  const float* epi_scale, const float* epi_shift, const float* epi_add, const float* bn_raw,
+                  const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
                   int TW, int MT, int NT, int flags, void* stream);

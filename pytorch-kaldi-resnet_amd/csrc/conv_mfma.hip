@@ -33,6 +33,9 @@ struct ConvArgs {
     const float* epi_scale;
     const float* epi_shift;
     const float* epi_add;
+    const float* bn_raw;   // SPK_EPI_BNBWD: raw conv output of the BatchNorm whose backward statistics are reduced here
+    const float* bn_act;   //   activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0)
+    const float* bn4;      //   [4][Cout]: mean, invstd, scale, shift of that BatchNorm
     float* stats;
     int B, IH, IW, Cin;
     int OH, OW;            // logical output grid
@@ -252,6 +255,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         es = *(const f32x4*)(a.epi_scale + n0 + qc * 4);
         eh = *(const f32x4*)(a.epi_shift + n0 + qc * 4);
     }
+    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bsc = bmu, bsh = bmu;
+    if (flags & SPK_EPI_BNBWD) {
+        bmu = *(const f32x4*)(a.bn4 + n0 + qc * 4);
+        bis = *(const f32x4*)(a.bn4 + a.Cout + n0 + qc * 4);
+        bsc = *(const f32x4*)(a.bn4 + 2 * a.Cout + n0 + qc * 4);
+        bsh = *(const f32x4*)(a.bn4 + 3 * a.Cout + n0 + qc * 4);
+    }
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -284,8 +294,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     v[3] = fmaxf(v[3], 0.f);
                 }
                 *(f32x4*)dst = v;
-                ssum += v;
-                ssq += v * v;
+                if (flags & SPK_EPI_BNBWD) {
+                    // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
+                    // its backward needs no separate reduction pass over this tensor
+                    const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
+                    f32x4 m;
+                    if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
+                    else m = rw * bsc + bsh;
+                    f32x4 dz;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                    ssum += dz;
+                    ssq += dz * ((rw - bmu) * bis);
+                } else {
+                    ssum += v;
+                    ssq += v * v;
+                }
             }
         }
     }
@@ -316,7 +340,8 @@ static int launch_conv(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 
 extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale,
                              const float* in_shift, const float* epi_scale, const float* epi_shift,
-                             const float* epi_add, float* stats, int B, int IH, int IW, int Cin, int OH,
+                             const float* epi_add, const float* bn_raw, const float* bn_act, const float* bn4,
+                             float* stats, int B, int IH, int IW, int Cin, int OH,
                              int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
                              const int* tap_dy, const int* tap_dx, const int* tap_w, int TH, int TW, int MT,
                              int NT, int flags, void* stream) {
@@ -334,9 +359,12 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(!(flags & SPK_EPI_AFFINE) || (epi_scale && epi_shift), "spk_conv_mfma: EPI_AFFINE needs scale/shift");
     SPK_REQUIRE(!(flags & SPK_EPI_ADD) || epi_add, "spk_conv_mfma: EPI_ADD needs epi_add");
     SPK_REQUIRE(!(flags & SPK_EPI_STATS) || stats, "spk_conv_mfma: EPI_STATS needs a stats buffer");
+    SPK_REQUIRE(!(flags & SPK_EPI_BNBWD) || ((flags & SPK_EPI_STATS) && bn_raw && bn4),
+                "spk_conv_mfma: EPI_BNBWD needs EPI_STATS, bn_raw and bn4");
     ConvArgs a;
     a.in = in; a.wpk = wpk; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift;
     a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;
+    a.bn_raw = bn_raw; a.bn_act = bn_act; a.bn4 = bn4;
     a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
     a.IS = IS; a.OS = OS; a.ooy = ooy; a.oox = oox; a.TH = TH; a.TW = TW;
     a.tiles_y = spk_ceil_div(OH, TH); a.tiles_x = spk_ceil_div(OW, TW);

@@ -100,6 +100,8 @@ class Engine:
         # HBM-bound BatchNorm-backward passes of the main dgrad chain
         self.wgrad_stream = None
         self.use_side_stream = True
+        # BatchNorm-backward reductions come out of the producing data-gradient epilogue (EPI_BNBWD) where possible
+        self.fuse_bn_reduce = True
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def _all_convs(self):
@@ -309,8 +311,15 @@ class Engine:
             stage_of = []
             for li in range(1, 5):
                 stage_of += [li] * len(getattr(m.res, "layer%d" % li))
+            part = None      # BatchNorm-backward partial sums of `d`, when the producing dgrad epilogue made them
             for bi in range(nblk - 1, -1, -1):
-                d = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc)
+                # the gradient this block hands down is the gradient wrt the previous block's (or the stem's)
+                # BN+ReLU output: let the data-gradient epilogue reduce that BatchNorm's backward statistics
+                if bi > 0:
+                    prev = (saved["blocks"][bi - 1]["raws"][-1], self.blocks[bi - 1].bns[-1].t4)
+                else:
+                    prev = (saved["raw0"], self.stem_bn.t4)
+                d, part = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc, part, prev)
                 saved["blocks"][bi] = None
                 if on_stage_done and (bi == 0 or stage_of[bi - 1] != stage_of[bi]):
                     self._join_wgrad()
@@ -318,32 +327,44 @@ class Engine:
             # stem: d is the gradient wrt relu(bn(raw0))
             bn = self.stem_bn
             draw0 = ops.bn_backward(d, saved["raw0"], None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad,
-                                    MASK_RAW, draw_out=d, accumulate=acc)
+                                    MASK_RAW, draw_out=d, accumulate=acc, partial=part)
             ops.stem_wgrad(saved["x"], draw0, self.stem_conv.h.weight.grad, accumulate=acc)
             self._join_wgrad()
             if on_stage_done:
                 on_stage_done("stem")
 
-    def _block_bwd(self, b, rec, dout, acc):
+    def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None):
+        """-> (gradient wrt the block input, BN-backward partial sums of it or None)."""
         x, raws, out = rec["x"], rec["raws"], rec["out"]
         n = len(b.convs)
         # last BN (+ residual + relu): dz is written over dout and is the shortcut gradient
         bn = b.bns[n - 1]
         draw = ops.bn_backward(dout, raws[n - 1], out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
-                               dz_out=dout, accumulate=acc)
+                               dz_out=dout, accumulate=acc, partial=dout_partial)
         dz = dout
         for i in range(n - 1, 0, -1):
             c, pbn = b.convs[i], b.bns[i - 1]
             # conv i consumed relu(bn_{i-1}(raw_{i-1})) through its fused input transform
             self._wgrad(raws[i - 1], draw, c.h.weight.grad, c.k, c.stride, in_affine=(pbn.t4[2], pbn.t4[3]),
                         accumulate=acc)
-            da = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (raws[i - 1].shape[1], raws[i - 1].shape[2]))
+            hw = (raws[i - 1].shape[1], raws[i - 1].shape[2])
+            if c.stride == 1 and self.fuse_bn_reduce:
+                # dgrad epilogue also reduces (sum dz, sum dz*xhat) of bn_{i-1}: no separate pass over da / raw
+                da, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, 1, hw, bn_bwd=(raws[i - 1], None, pbn.t4))
+            else:
+                da, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw), None
             draw = ops.bn_backward(da, raws[i - 1], None, pbn.t4, pbn.h.weight.data, pbn.h.weight.grad, pbn.h.bias.grad,
-                                   MASK_RAW, draw_out=da, accumulate=acc)
+                                   MASK_RAW, draw_out=da, accumulate=acc, partial=part)
         c = b.convs[0]
         self._wgrad(x, draw, c.h.weight.grad, c.k, c.stride, accumulate=acc)
+        part = None
         if b.ds is None:
-            dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]), add=dz)
+            if c.stride == 1 and self.fuse_bn_reduce and prev is not None:
+                # x is the previous block's relu(bn(raw) + shortcut) (or the stem's relu(bn(raw0))): mask = x > 0
+                dx, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, 1, (x.shape[1], x.shape[2]), add=dz,
+                                          bn_bwd=(prev[0], x, prev[1]))
+            else:
+                dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]), add=dz)
         else:
             dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]))
             cd, bnd = b.ds
@@ -351,7 +372,7 @@ class Engine:
                                     MASK_NONE, draw_out=dz, accumulate=acc)
             self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
             ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True)
-        return dx
+        return dx, part
 
     # ---- fused training step (forward + CE + backward, no autograd graph) --------------------------------------
     def loss_and_grad(self, x, y, on_stage_done=None):

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import hip, tiling
-from .hip import (EPI_ADD, EPI_AFFINE, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, MASK_ACT, MASK_NONE, MASK_RAW,
+from .hip import (EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, MASK_ACT, MASK_NONE, MASK_RAW,
                   call, ptr, stream)
 
 BN_EPS = 1e-5
@@ -46,7 +46,8 @@ def pack_conv_weight(w, transpose=False, out=None):
     return out
 
 
-def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats):
+def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
+                 bn_bwd=None):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -64,6 +65,10 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     if relu:
         flags |= EPI_RELU
     stats = None
+    if bn_bwd is not None:
+        want_stats = True
+        flags |= EPI_BNBWD
+        assert bn_bwd[0].shape == out.shape and (bn_bwd[1] is None or bn_bwd[1].shape == out.shape)
     if want_stats:
         flags |= EPI_STATS
         ntile = 4 * B * (-(-OH // TH)) * (-(-OW // TW))      # one partial row per wave
@@ -71,7 +76,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     call("spk_conv_mfma", ptr(x), ptr(wpk), ptr(out),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
-         ptr(epi_add), ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
+         ptr(epi_add), ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
+         ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream(),
          label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
@@ -92,9 +98,11 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
     return out, st
 
 
-def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False):
+def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None):
     """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
-    `add` (same shape as dx) is summed in the epilogue; accumulate=True adds onto the existing `out`."""
+    `add` (same shape as dx) is summed in the epilogue; accumulate=True adds onto the existing `out`.
+    bn_bwd = (raw, act or None, bn4[4][Cin]) (stride-1 only): dx is the gradient wrt the output of that BatchNorm
+    (+ReLU); the launch also returns the BatchNorm-backward partial sums -> (dx, partial)."""
     B, OH, OW, Cout = dy.shape
     IH, IW = in_hw
     if out is None:
@@ -108,9 +116,9 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             taps = [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
         else:
             taps = [(0, 0, 0)]
-        _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False)
-        return out
-    assert stride == 2
+        st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd)
+        return (out, st) if bn_bwd is not None else out
+    assert stride == 2 and bn_bwd is None
     if ksize == 1:
         # only even input pixels receive gradient from a strided 1x1 conv
         if not accumulate:
@@ -234,16 +242,21 @@ def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None):
     return out
 
 
-def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False):
+def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,
+                partial=None):
     """Full BN backward (reduce -> finalize -> apply). bn4 = [mean, invstd, scale, shift] rows.
-    Returns draw (gradient wrt the raw conv output)."""
+    `partial`: (sum dz, sum dz*xhat) rows already produced by the data-gradient epilogue (EPI_BNBWD) - skips the
+    reduction pass.  Returns draw (gradient wrt the raw conv output)."""
     C = raw.shape[-1]
     N = raw.numel() // C
-    nblk = hip.lib().spk_bn_stats_blocks(N, C)
-    part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
     coef = torch.empty(3, C, device=raw.device, dtype=torch.float32)
-    call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
-         N, C, mask_mode, stream())
+    if partial is None:
+        nblk = hip.lib().spk_bn_stats_blocks(N, C)
+        part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
+        call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
+             N, C, mask_mode, stream())
+    else:
+        part, nblk = partial, partial.shape[0]
     call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
          1 if accumulate else 0, ptr(_ws64(raw.device)), stream())
     if draw_out is None:

@@ -102,6 +102,25 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), out=dx3, accumulate=True)
     e = relerr(nchw(dx3), gx + addt)
     assert e < 2e-5, "dgrad accumulate %g" % e
+    # data gradient with the fused BatchNorm-backward reduction (EPI_BNBWD): partial rows must sum to
+    # (sum dz, sum dz*xhat) with dz = dx * mask, for both mask sources
+    if s == 1:
+        rawt = rnd(10, B, Cin, H, Wd, scale=2.0, shift=0.3)
+        bn4 = torch.stack([rnd(11, Cin, scale=0.3), rnd(12, Cin, scale=0.2, shift=1.0), rnd(13, Cin, scale=0.5, shift=1.0),
+                           rnd(14, Cin, scale=0.4)])
+        actt = rnd(15, B, Cin, H, Wd)
+        for act in (None, actt):
+            dxb, part = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt),
+                                       bn_bwd=(nhwc(rawt), None if act is None else nhwc(act), bn4.cuda()))
+            assert relerr(nchw(dxb), gx + addt) < 2e-5
+            v = (gx + addt).double()
+            mask = ((rawt * bn4[2].view(1, -1, 1, 1) + bn4[3].view(1, -1, 1, 1)) > 0) if act is None else (act > 0)
+            dzr = v * mask
+            xh = (rawt.double() - bn4[0].view(1, -1, 1, 1)) * bn4[1].view(1, -1, 1, 1)
+            tot = part.double().sum(0).cpu()
+            ref0, ref1 = dzr.sum((0, 2, 3)), (dzr * xh).sum((0, 2, 3))
+            assert float((tot[:, 0] - ref0).abs().max() / ref0.abs().max()) < 1e-4
+            assert float((tot[:, 1] - ref1).abs().max() / ref1.abs().max()) < 1e-4
     # weight gradient (plain and with the fused input transform)
     dw = torch.empty(Cout, Cin, k, k, device="cuda")
     ops.conv_wgrad(xg, nhwc(dy), dw, k, s)
