@@ -1,0 +1,24 @@
+/* libspkio - native batch ingest of Kaldi float32 matrices (host-side C ABI, no device code).
+ * Replaces, for fixed-length training batches, the per-sample path of the reference:
+ *   kaldi_io.read_mat (scripts/kaldi_io.py:376-410, open_or_fd :41-71) -> random crop + transpose
+ *   (scripts/datasets.py:59-72) -> default collate.
+ * All pointers are HOST pointers; `out` should be pinned memory so the H2D copy can be asynchronous. */
+#ifndef SPKIO_H
+#define SPKIO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+int spk_io_version(void);
+const char* spk_io_last_error(void);
+/* parse n matrix headers at (paths[i], offsets[i]) (the scp's "path:offset"): rows, cols, payload offset */
+int spk_ark_probe(int n, const char* const* paths, const int64_t* offsets, int32_t* rows, int32_t* cols,
+                  int64_t* data_offsets);
+/* out[b][f][t] = M_b[starts[b] + t][f], t < T; reads only the cropped frames with pread() on `nthreads` threads */
+int spk_ark_read_crop(int B, const char* const* paths, const int64_t* data_offsets, const int32_t* rows,
+                      const int32_t* starts, int F, int T, float* out, int nthreads);
+void spk_ark_close_all(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

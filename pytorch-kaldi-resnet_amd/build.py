@@ -17,6 +17,9 @@ def needs_build():
     for f in os.listdir(CSRC):
         if os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
+    io_lib = os.path.join(HERE, "libspkio.so")
+    if not os.path.exists(io_lib) or os.path.getmtime(os.path.join(HERE, "csrc_io", "ark_reader.cpp")) > os.path.getmtime(io_lib):
+        return True
     return False
 
 
@@ -40,6 +43,9 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed on %s" % s)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    # host-only ingest library (no device code)
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-shared", "-std=c++17", "-pthread",
+                           os.path.join(HERE, "csrc_io", "ark_reader.cpp"), "-o", os.path.join(HERE, "libspkio.so")])
     if verbose:
         print("built", LIB)
     return LIB

@@ -60,6 +60,9 @@ parser.add_argument("--gpu", default=None, type=int)
 parser.add_argument("--gpu-num", default=-1, type=int)
 parser.add_argument("--multiprocessing-distributed", action="store_true")
 parser.add_argument("--max-steps", default=-1, type=int, help="stop each epoch after N steps (smoke runs)")
+parser.add_argument("--native-reader", action="store_true",
+                    help="read training batches with the native C++ ark reader (libspkio: pread of the cropped frames on a "
+                         "thread pool into pinned memory) instead of Dataset/DataLoader worker processes; --dataset v1 only")
 parser.add_argument("--no-graph", action="store_true",
                     help="launch kernels eagerly (stage-bucketed all-reduce overlapped with backward) instead of replaying "
                          "the step as one hipGraph followed by one flat all-reduce")
@@ -147,14 +150,21 @@ def main_worker(gpu, ngpus_per_node, args):
 
     DS = SequenceDataset2 if args.dataset == "v2" else SequenceDataset
     chunk = args.max_chunk_size if args.dataset == "v2" else [args.max_chunk_size]
-    train_dataset = DS(scp_file=args.train_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
     train_sampler = None
-    if args.distributed:
-        train_sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, num_replicas=args.world_size,
-                                                                        rank=args.rank, shuffle=True)
-    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=(train_sampler is None),
-                                               num_workers=args.workers, pin_memory=True, sampler=train_sampler,
-                                               drop_last=False)
+    if args.native_reader and args.dataset != "v2":
+        from pytorch_kaldi_resnet_amd.ingest import NativeTrainLoader
+        train_loader = NativeTrainLoader(args.train_list, args.utt2spkid, args.max_chunk_size, args.batch_size,
+                                         rank=max(args.rank, 0), world=world, seed=args.seed or 0,
+                                         threads=max(1, args.workers))
+        train_sampler = train_loader          # set_epoch() reshuffles, like DistributedSampler
+    else:
+        train_dataset = DS(scp_file=args.train_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
+        if args.distributed:
+            train_sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, num_replicas=args.world_size,
+                                                                            rank=args.rank, shuffle=True)
+        train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size,
+                                                   shuffle=(train_sampler is None), num_workers=args.workers,
+                                                   pin_memory=True, sampler=train_sampler, drop_last=False)
     print("=> args.world_size: {}, args.rank: {}, args.batch_size: {}, train_loader samples: {}".format(
         args.world_size, args.rank, args.batch_size, len(train_loader)))
     val = DS(scp_file=args.cv_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
@@ -165,7 +175,7 @@ def main_worker(gpu, ngpus_per_node, args):
         return
     os.makedirs(args.log_dir, exist_ok=True)
     for epoch in range(args.start_epoch, args.epochs):
-        if args.distributed:
+        if train_sampler is not None:
             train_sampler.set_epoch(epoch)
         train(train_loader, model, optimizer, reducer, epoch, args, world)
         acc1 = validate(val_loader, model, args)

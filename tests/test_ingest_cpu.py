@@ -1,0 +1,89 @@
+"""Native ingest (libspkio) against the Python reader: bit-exact crops, sampling semantics, error behaviour."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_kaldi_resnet_amd  # noqa: F401
+from pytorch_kaldi_resnet_amd import ingest, kaldi_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _corpus(tmp_path, n_spk=4, per=5, F=12):
+    rs = np.random.RandomState(3)
+    ark = str(tmp_path / "f.ark")
+    scp, u2s, mats = [], [], {}
+    with open(ark, "wb") as f:
+        for s in range(n_spk):
+            for u in range(per if s else 2 * per):      # speaker 0 has twice the utterances -> balancing kicks in
+                utt = "s%d-u%d" % (s, u)
+                m = rs.randn(rs.randint(30, 50), F).astype(np.float32)
+                off = kaldi_io.write_mat(f, m, key=utt)
+                scp.append("%s %s:%d" % (utt, ark, off))
+                u2s.append("%s %d" % (utt, s))
+                mats[utt] = m
+    open(str(tmp_path / "f.scp"), "w").write("\n".join(scp) + "\n")
+    open(str(tmp_path / "u2s"), "w").write("\n".join(u2s) + "\n")
+    return str(tmp_path / "f.scp"), str(tmp_path / "u2s"), mats, scp
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "spkio.h")).read()
+    for name in set(re.findall(r"\b(spk_[a-z_]+)\s*\(", hdr)):
+        assert hasattr(ingest.lib(), name), name
+
+
+def test_read_crop_is_bit_exact(tmp_path):
+    scp, u2s, mats, lines = _corpus(tmp_path)
+    rx = [l.split()[1] for l in lines]
+    tab = ingest.ArkTable(rx)
+    for i, l in enumerate(lines):
+        assert tab.rows[i] == mats[l.split()[0]].shape[0] and tab.cols[i] == 12
+    idx = np.array([0, 5, 7, 11, 3])
+    starts = [0, 4, 10, 2, int(tab.rows[3]) - 20]
+    out = torch.empty(5, 12, 20)
+    tab.read_crop(idx, starts, 20, out, nthreads=3)
+    for b, (i, s) in enumerate(zip(idx, starts)):
+        ref = kaldi_io.read_mat(rx[i])[s:s + 20].T
+        np.testing.assert_array_equal(out[b].numpy(), ref)
+    with pytest.raises(RuntimeError, match="outside utterance"):
+        tab.read_crop(idx[:1], [int(tab.rows[0]) - 5], 20, torch.empty(1, 12, 20))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        ingest.ArkTable(["/nonexistent/x.ark:0"])
+    bad = str(tmp_path / "d.ark")
+    with open(bad, "wb") as f:
+        off = kaldi_io.write_mat(f, np.zeros((3, 2)), key="k")      # float64 'DM ' is refused by the native reader
+    with pytest.raises(RuntimeError, match="float32"):
+        ingest.ArkTable(["%s:%d" % (bad, off)])
+
+
+def test_loader_semantics(tmp_path):
+    scp, u2s, mats, lines = _corpus(tmp_path)
+    # speaker 0: 10 utts, others 5 -> cap = min(500, (10+1)//2) = 5 -> rep = max(1, 5//10)=1 for spk0, 1 for others
+    ld = ingest.NativeTrainLoader(scp, u2s, 16, batch_size=4, seed=1)
+    assert len(ld.labels) == 25 and len(ld) == 7
+    seen, nb = 0, 0
+    for x, y in ld:
+        assert x.shape[1:] == (12, 16) and x.dtype == torch.float32 and y.dtype == torch.int64
+        seen += x.shape[0]
+        nb += 1
+    assert seen == 25 and nb == 7
+    # two ranks: disjoint shards covering everything (+ wrap-around padding), reshuffled per epoch
+    a = ingest.NativeTrainLoader(scp, u2s, 16, 4, rank=0, world=2, seed=1)
+    b = ingest.NativeTrainLoader(scp, u2s, 16, 4, rank=1, world=2, seed=1)
+    ia, ib = a._indices(), b._indices()
+    assert len(ia) == len(ib) == 13 and set(ia) | set(ib) == set(range(25))
+    a.set_epoch(1)
+    assert not np.array_equal(a._indices(), ia)
+    # every crop is a real window of its utterance
+    ld2 = ingest.NativeTrainLoader(scp, u2s, 30, batch_size=25, seed=2)
+    (x, y), = list(ld2)
+    allm = list(mats.values())
+    for i in range(25):
+        w = x[i].numpy().T
+        assert any(any(np.array_equal(w, m[s:s + 30]) for s in range(m.shape[0] - 29)) for m in allm if m.shape[0] >= 30)
+    with pytest.raises(AssertionError):
+        ingest.NativeTrainLoader(scp, u2s, 60, 4)

@@ -47,7 +47,8 @@ def test_train_decode_score_pipeline(tmp_path):
                           "--lr", "0.01", "--lr-final", "0.001", "--wd", "5e-4", "--max-chunk-size", "200",
                           "--train-list", os.path.join(d, "train.scp"), "--cv-list", os.path.join(d, "cv.scp"),
                           "--spk-num", str(n_spk), "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "7",
-                          "--log-dir", os.path.join(d, "exp")], env=env, capture_output=True, text=True, timeout=600)
+                          "--native-reader", "--log-dir", os.path.join(d, "exp")], env=env, capture_output=True, text=True,
+                         timeout=600)
     assert log.returncode == 0, log.stdout[-3000:] + log.stderr[-3000:]
     assert "Epoch: [1][" in log.stdout and " * Acc@1 " in log.stdout
     # model_best.pth.tar only appears once cv Acc@1 > 0 (reference semantics: is_best = acc1 > best_acc1 = 0)
