@@ -72,6 +72,28 @@ def cpu_baseline(args):
                       "(%.2f s/step)" % (args.cpu_steps, bs, args.frames, FEAT, SPK, torch.__version__, dt)}
 
 
+def embedding_parity(dev):
+    """BASELINE's second metric: max (1 - cosine) between HIP predict() and the CPU oracle on a seeded batch
+    (hashed weights, 4 utterances x 200 frames x 80 mel, eval mode).  The oracle is only the checker here."""
+    import contextlib
+
+    import numpy as np
+    from oracle import spk_oracle as O
+    from oracle import weights as W
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    npst = W.make_state(11, 10, FEAT, "mean+std", "AAM", "resnet34")
+    with contextlib.redirect_stdout(sys.stderr):
+        m = NeuralSpeakerModel(10, FEAT, "mean+std", "AAM", 0.2, 30)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in npst.items()})
+    m = m.to(dev).eval()
+    x, _ = W.make_input(12, 4, FEAT, 200, 10)
+    with torch.no_grad():
+        e = m.predict(torch.from_numpy(x).to(dev)).cpu().numpy().astype(np.float64)
+        r = O.embed(O.to_torch_state(npst), torch.from_numpy(x), "mean+std", "resnet34", train=False).numpy().astype(np.float64)
+    cos = (e * r).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(r, axis=1))
+    return float((1.0 - cos).max())
+
+
 def log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
     sys.stderr.flush()
@@ -227,10 +249,13 @@ def main():
                                         "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
                                         "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
         log("roofline pass done; timing the CPU oracle (bounded sample)")
         cpu = cpu_baseline(args)
         log("cpu baseline done")
+        parity = embedding_parity(dev)
+        log("embedding parity vs oracle: max 1-cos = %.3e" % parity)
     if rank == 0:
         gb = args.batch * world
         out = {
@@ -246,6 +271,7 @@ def main():
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed is not None else "eager"},
             "final_loss": round(lossv, 4),
             "roofline": roofline, "cpu_baseline": cpu,
+            "embedding_cosine_delta_vs_oracle": parity,
         }
         print(json.dumps(out))
     if world > 1:
