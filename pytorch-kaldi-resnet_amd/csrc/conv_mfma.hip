@@ -55,12 +55,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-#ifdef PRIO_STAGGER
-    // Two blocks share a CU (one wave each per SIMD) and run the same program: at equal priority they advance in
-    // lockstep and reach their staging/barrier phases together, leaving the matrix pipe idle.  A static priority
-    // for every other dispatch round breaks the symmetry: the favoured wave keeps the pipe, the other fills its gaps.
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
     // order (same pixel region, next cout group; then the neighbouring region) share an XCD's L2.

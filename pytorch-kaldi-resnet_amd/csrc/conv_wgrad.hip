@@ -39,9 +39,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar registers, scalar branches
     const int r = lane & 31, h = lane >> 5;
     const int wk = wave / WN, wn = wave % WN;
-#ifdef PRIO_STAGGER
-    if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
     const int ci0 = blockIdx.y * 32;
     const int co0 = blockIdx.z * (32 * WN);
     const int halo_pix = a.halo_h * a.halo_w;

@@ -53,7 +53,10 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     dys = [t[0] for t in taps]
     dxs = [t[1] for t in taps]
     tws = [t[2] for t in taps]
-    TH, TW, MT, NT = tiling.conv_tile(OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
+    key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
+    if tiling.AUTOTUNE and key not in tiling.FORCE_CONV and PROFILE is None and not torch.cuda.is_current_stream_capturing():
+        _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu)
+    TH, TW, MT, NT = tiling.conv_tile(*key)
     flags = 0
     if in_affine is not None:
         flags |= IN_AFFINE_RELU
@@ -81,6 +84,54 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream(),
          label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
+
+
+def _time_launch(fn, reps=2):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu):
+    """Time candidate tiles on the real operands (scratch output) and pin the fastest for this launch shape."""
+    scratch = torch.empty_like(out)
+    add = epi_add if (epi_add is None or epi_add.data_ptr() != out.data_ptr()) else scratch
+    best = None
+    for cand in tiling.conv_candidates(*key):
+        tiling.FORCE_CONV[key] = cand
+        try:
+            ms = _time_launch(lambda: _conv_launch(x, wpk, scratch, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine,
+                                                   epi_affine, add, relu, True))
+        except RuntimeError:
+            continue
+        if best is None or ms < best[0]:
+            best = (ms, cand)
+    if best is None:
+        del tiling.FORCE_CONV[key]
+    else:
+        tiling.FORCE_CONV[key] = best[1]
+
+
+def _autotune_wgrad(key, x, dy, ksize, stride, in_affine):
+    scratch = torch.empty(dy.shape[3], x.shape[3], ksize, ksize, device=x.device, dtype=torch.float32)
+    best = None
+    for cand in tiling.wgrad_candidates(*key):
+        tiling.FORCE_WGRAD[key] = cand
+        try:
+            ms = _time_launch(lambda: conv_wgrad(x, dy, scratch, ksize, stride, in_affine=in_affine))
+        except RuntimeError:
+            continue
+        if best is None or ms < best[0]:
+            best = (ms, cand)
+    if best is None:
+        del tiling.FORCE_WGRAD[key]
+    else:
+        tiling.FORCE_WGRAD[key] = best[1]
 
 
 def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_add=None, relu=False, stats=False,
@@ -163,6 +214,10 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy."""
     B, IH, IW, Cin = x.shape
     _, OH, OW, Cout = dy.shape
+    wkey = (OH, OW, Cin, Cout, ksize, stride)
+    if tiling.AUTOTUNE and wkey not in tiling.FORCE_WGRAD and PROFILE is None and not torch.cuda.is_current_stream_capturing():
+        tiling.FORCE_WGRAD[wkey] = tiling._wgrad_tile(*wkey)      # placeholder: stops the recursion below
+        _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
     TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride)
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
     nsplit = tiling.wgrad_nsplit(nreg, Cin, Cout, WN)

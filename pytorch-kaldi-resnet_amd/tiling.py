@@ -5,11 +5,18 @@ pixels per wave, 4 waves) and NT*32 output channels; its input halo tile lives i
 pixel.  The chooser minimises a cycle model: MFMA time of the padded region plus staging time of the
 halo, with penalties for configurations that cut occupancy (registers at MT*NT >= 8, LDS > 52 KiB).
 """
+import os as _os
 from functools import lru_cache
 
 LDS_PIX_BYTES = 144
 LDS_SOFT = 52 * 1024      # 3 blocks / CU
 LDS_HARD = 80 * 1024      # 2 blocks / CU
+
+
+# prefetch-window limits of conv_wgrad_kernel (csrc/conv_wgrad.hip: WGRAD_NX = 5, WGRAD_ND = 4; also exported as
+# spk_conv_wgrad_limits): the next region must fit in 9 float4 registers per thread
+WGRAD_MAX_HALO = 32 * 5
+WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
 
 
 # Measured overrides (tools/conv_bench.py --sweep on MI355X): key -> (TH, TW, MT, NT) / (TH, TW, WN)
@@ -27,6 +34,48 @@ def _load_table():
             FORCE_CONV[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("wgrad", {}).items():
             FORCE_WGRAD[tuple(int(x) for x in k.split(","))] = tuple(v)
+
+
+# Autotune on first use (the analogue of the reference's `cudnn.benchmark = True`, scripts/train_resnet.py:231):
+# when enabled, ops.py times a handful of candidate tiles the first time a launch shape is seen and caches the winner.
+AUTOTUNE = _os.environ.get("SPK_AUTOTUNE", "0") == "1"
+
+
+def conv_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_config=3):
+    """Candidate (TH, TW, MT, NT) tiles: for every register configuration the best-utilised few shapes."""
+    cands = []
+    for MT in (1, 2, 3, 4):
+        cap = 128 * MT
+        for NT in (1, 2, 4):
+            if Cout % (32 * NT) or MT * NT > 8 or (MT * NT == 8 and MT == 4):
+                continue
+            best = []
+            for TH in range(1, min(OH, cap) + 1):
+                for TW in range(1, min(OW, cap // TH) + 1):
+                    halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
+                    if halo * LDS_PIX_BYTES > LDS_HARD:
+                        continue
+                    ty, tx = -(-OH // TH), -(-OW // TW)
+                    best.append((-(OH * OW) / (ty * tx * cap), halo / (TH * TW), TH, TW))
+            best.sort()
+            cands += [(TH, TW, MT, NT) for _, _, TH, TW in best[:per_config]]
+    return cands
+
+
+def wgrad_candidates(OH, OW, Cin, Cout, ksize, stride, per_config=4):
+    out = []
+    OWe = OW + (OW & 1)
+    for WN in ((1,) if Cout == 32 else (1, 2)):
+        c = []
+        for TH in range(1, OH + 1):
+            for TW in range(2, OWe + 1, 2):
+                if TH * TW > WGRAD_MAX_TILE[WN] or ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) > WGRAD_MAX_HALO:
+                    continue
+                ty, tx = -(-OH // TH), -(-OW // TW)
+                c.append((ty * tx * (TH * TW + 24.0), TH, TW))
+        c.sort()
+        out += [(TH, TW, WN) for _, TH, TW in c[:per_config]]
+    return out
 
 
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
@@ -78,12 +127,6 @@ def _conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
     return best[1]
 
 
-# prefetch-window limits of conv_wgrad_kernel (csrc/conv_wgrad.hip: WGRAD_NX = 5, WGRAD_ND = 4; also exported as
-# spk_conv_wgrad_limits): the next region must fit in 9 float4 registers per thread
-WGRAD_MAX_HALO = 32 * 5
-WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
-
-
 @lru_cache(maxsize=None)
 def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
     """-> (TH, TW, WN).  TW even; halo <= WGRAD_MAX_HALO pixels, tile <= WGRAD_MAX_TILE[WN] pixels."""
@@ -107,7 +150,6 @@ def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
     return best[1]
 
 
-import os as _os
 WGRAD_TARGET_BLOCKS = int(_os.environ.get('SPK_WGRAD_BLOCKS', '512'))      # persistent wgrad blocks per launch = 2 per CU x 256 CUs (measured best of 512/768/1024)
 
 

@@ -98,6 +98,8 @@ def main_worker(gpu, ngpus_per_node, args):
 
     args.gpu = gpu
     print("Use GPU: {} for training".format(args.gpu))
+    from pytorch_kaldi_resnet_amd import tiling
+    tiling.AUTOTUNE = True        # like `cudnn.benchmark = True` (reference train_resnet.py:231): tune tiles on first use
     if args.distributed:
         if args.dist_url == "env://" and args.rank == -1:
             args.rank = int(os.environ["RANK"])

@@ -59,27 +59,7 @@ for i, (c, h, w) in enumerate(dims):
 
 
 def conv_candidates(OH, OW, IS, ks, Cout):
-    cands = set()
-    for MT in (1, 2, 3, 4):
-        cap = 128 * MT
-        for NT in (1, 2, 4):
-            if Cout % (32 * NT):
-                continue
-            if MT * NT > 8:
-                continue
-            best = []
-            for TH in range(1, min(OH, cap) + 1):
-                for TW in range(1, min(OW, cap // TH) + 1):
-                    halo = ((TH - 1) * IS + ks) * ((TW - 1) * IS + ks)
-                    if halo * 144 > 150 * 1024:
-                        continue
-                    ty, tx = -(-OH // TH), -(-OW // TW)
-                    util = OH * OW / (ty * tx * cap)
-                    best.append((-util, halo / (TH * TW), TH, TW))
-            best.sort()
-            for u, hr, TH, TW in best[:6]:
-                cands.add((TH, TW, MT, NT))
-    return sorted(cands)
+    return sorted(set(tiling.conv_candidates(OH, OW, IS, ks, ks, ks * ks, Cout, per_config=6)))
 
 
 table = {"conv": {}, "wgrad": {}}
