@@ -230,6 +230,33 @@ def test_sgd_loss_curve(P, gold_dir, name):
     assert cos_dist(e2, g["emb_after"]) < 1e-4
 
 
+@pytest.mark.parametrize("arch,F,T,B,pooling,loss", [("resnet18", 30, 37, 3, "mean+std", "AAM"), ("resnet34", 80, 64, 1, "mean", "softmax"),
+                                                    ("resnet50", 24, 45, 2, "mean+std", "AAM-v1"), ("resnet18", 80, 1001, 1, "mean+std", "AAM")])
+def test_odd_shapes_against_oracle(P, arch, F, T, B, pooling, loss):
+    """Ragged / minimal shapes the reference handles implicitly: feat_dim not a multiple of 8 (ceil at every stride-2
+    stage, fc1 fan-in (F+7)//8), odd frame counts, batch 1, a long utterance (decode.py feeds whole utterances)."""
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    S = 7
+    npst = W.make_state(21, S, F, pooling, loss, arch)
+    m = NeuralSpeakerModel(S, F, pooling, loss, 0.2, 30, arch=arch)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in npst.items()})
+    m = m.cuda()
+    x, y = W.make_input(22, B, F, T, S)
+    st = O.to_torch_state(npst)
+    m.eval()
+    with torch.no_grad():
+        e = m.predict(torch.from_numpy(x).cuda()).cpu().numpy()
+        eo = O.embed(st, torch.from_numpy(x), pooling, arch, train=False).numpy()
+    assert e.shape == (B, 256) and cos_dist(e, eo) < 1e-6 and srel(e, eo) < 3e-5
+    if B > 1:      # train-mode BN needs more than one value per channel in the head's BatchNorm1d
+        m.train()
+        lg = m(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+        lo = O.forward(st, torch.from_numpy(x), torch.from_numpy(y), pooling, loss, arch, train=True)
+        assert srel(lg.detach().cpu().numpy(), lo.detach().numpy()) < 2e-4
+        torch.nn.functional.cross_entropy(lg, torch.from_numpy(y).cuda()).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
 def test_cpu_input_is_refused(P):
     from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
     m = NeuralSpeakerModel(5, 80, "mean+std", "AAM").cuda()
