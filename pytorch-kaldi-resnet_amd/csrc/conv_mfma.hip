@@ -16,6 +16,8 @@
 // GEMM view: M = pixels (rows of the 32x32 tile), N = cout (lanes), K = (tap, cin).
 // K is consumed 8 at a time: one ds_read_b128 + one global_load_dwordx4 feed four MFMAs, the
 // two lane halves taking cin {0..3} and {4..7} of the group (any K order is a valid sum).
+// (ABL_NO_* macros select diagnostic ablation builds - wrong results by construction - used to price each phase of the
+//  kernel: SPK_CXXFLAGS="-DABL_NO_STAGE" python build.py, then SPK_LIB=<variant.so> tools/conv_bench.py.)
 #include "spk_common.h"
 
 #define CK 32

@@ -9,6 +9,8 @@
 // waves of a block are WK pixel-splits x WN cout tiles.  Blocks are persistent over pixel regions
 // (grid.x = nsplit) and emit one partial slab each; spk_wgrad_reduce sums the slabs in a fixed
 // order (deterministic) and writes OIHW.
+// (ABL_NO_* macros select diagnostic ablation builds - wrong results by construction - used to price each phase of the
+//  kernel: SPK_CXXFLAGS="-DABL_NO_STAGE" python build.py, then SPK_LIB=<variant.so> tools/conv_bench.py.)
 #include "spk_common.h"
 
 #ifndef WGRAD_NX
