@@ -56,6 +56,18 @@ def lib():
     """Load libspkhip.so (built by build.py / __graft_entry__.build())."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "SPK_LIB" not in os.environ:
+            # not built yet (fresh checkout): compile it now with hipcc; there is no other implementation to fall back to
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("spk_build", os.path.join(_HERE, "build.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.build(force=True, verbose=False)
+            except Exception as e:
+                raise RuntimeError("libspkhip.so is missing at %s and building it failed (%s). Run `python "
+                                   "__graft_entry__.py build` (hipcc --offload-arch=gfx950). There is no fallback path."
+                                   % (LIB_PATH, e))
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libspkhip.so is missing at %s: run `python __graft_entry__.py build` "
