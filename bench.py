@@ -275,6 +275,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()          # rank 0 is still in its instrumented pass while the others are done: leave together
         dist.destroy_process_group()
 
 
