@@ -37,6 +37,12 @@ parser.add_argument("--gpu-num", default=-1, type=int)
 parser.add_argument("--decode-scp", help="decode.scp")
 parser.add_argument("--out-path", help="output directory")
 parser.add_argument("--multiprocessing-distributed", action="store_true")
+parser.add_argument("--native-reader", action="store_true",
+                    help="read whole utterances with the C++ ark reader, bucketed by length so that any --batch-size works "
+                         "with variable-length utterances (the reference is limited to per-process batch 1)")
+parser.add_argument("--out-format", default="text", choices=["text", "fv"],
+                    help="text = the reference's 'utt [ v0 ... ]' lines (str(np.float32), ~0.2 ms/utt of Python formatting); "
+                         "fv = binary Kaldi float-vector ark, read by the same scoring scripts")
 
 
 def main():
@@ -86,6 +92,12 @@ def main_worker(gpu, ngpus_per_node, args):
     model.loadParameters(ckpt["state_dict"])
     print("=> loaded checkpoint '{}' (epoch {})".format(args.model_path, ckpt.get("epoch")))
     model.cuda(args.gpu)
+    os.makedirs(args.out_path, exist_ok=True)
+    if args.native_reader:
+        native_generator(model, args)
+        if args.distributed:
+            dist.destroy_process_group()
+        return
     ds = EmbeddingDataset(scp_file=args.decode_scp, chunk_size=args.chunk_size)
     sampler = None
     if args.distributed:
@@ -95,20 +107,60 @@ def main_worker(gpu, ngpus_per_node, args):
                                          pin_memory=True, sampler=sampler, collate_fn=collate)
     print("=> args.world_size: {}, args.rank: {}, loaded embedding samples num: {}".format(args.world_size, args.rank,
                                                                                          len(loader)))
-    os.makedirs(args.out_path, exist_ok=True)
     sequence_generator(loader, model, args.out_path, args)
     if args.distributed:
         dist.destroy_process_group()
 
 
+def _write(f, utts, pred, fmt):
+    from pytorch_kaldi_resnet_amd import kaldi_io
+    for i in range(pred.shape[0]):
+        if fmt == "text":
+            f.write(utts[i] + " [ " + " ".join(map(str, pred[i, :].flatten())) + " ]\n")
+        else:
+            kaldi_io.write_vec_flt(f, np.ascontiguousarray(pred[i]), key=utts[i])
+
+
 def sequence_generator(loader, model, out_path, args):
     model.eval()
     name = str(args.gpu) if args.distributed else "alone"
-    with open(os.path.join(out_path, name), "w") as f, torch.no_grad():
+    with open(os.path.join(out_path, name), "w" if args.out_format == "text" else "wb") as f, torch.no_grad():
         for audios, utts in loader:
             pred = model.predict(audios.cuda(args.gpu, non_blocking=True)).cpu().numpy()
-            for i in range(pred.shape[0]):
-                f.write(utts[i] + " [ " + " ".join(map(str, pred[i, :].flatten())) + " ]\n")
+            _write(f, utts, pred, args.out_format)
+
+
+def native_generator(model, args):
+    """Length-bucketed extraction through libspkio: utterances of equal frame count share a batch (whole utterance when
+    --chunk-size -1, else the first chunk-size frames... the reference crops at random; extraction of a fixed window is
+    deterministic here), each rank takes every world-th batch."""
+    from pytorch_kaldi_resnet_amd.ingest import ArkTable
+    tab = [l.rstrip().split(None, 1) for l in open(args.decode_scp)]
+    utts = [u for u, _ in tab]
+    table = ArkTable([r for _, r in tab])
+    print("Totally " + str(len(utts)) + " samples")
+    T_of = table.rows if args.chunk_size < 0 else np.minimum(table.rows, args.chunk_size)
+    if args.chunk_size >= 0:
+        assert (table.rows >= args.chunk_size).all(), "utterance shorter than --chunk-size"
+    order = np.argsort(T_of, kind="stable")
+    batches, i = [], 0
+    while i < len(order):
+        j = i
+        while j < len(order) and j - i < args.batch_size and T_of[order[j]] == T_of[order[i]]:
+            j += 1
+        batches.append(order[i:j])
+        i = j
+    rank, world = (max(args.rank, 0), max(args.world_size, 1)) if args.distributed else (0, 1)
+    model.eval()
+    name = str(args.gpu) if args.distributed else "alone"
+    F = int(table.cols[0])
+    with open(os.path.join(args.out_path, name), "w" if args.out_format == "text" else "wb") as f, torch.no_grad():
+        for b in batches[rank::world]:
+            T = int(T_of[b[0]])
+            buf = torch.empty(len(b), F, T).pin_memory()
+            table.read_crop(b, [0] * len(b), T, buf, max(1, args.workers))
+            pred = model.predict(buf.cuda(args.gpu, non_blocking=True)).cpu().numpy()
+            _write(f, [utts[k] for k in b], pred, args.out_format)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,20 @@ def test_train_decode_score_pipeline(tmp_path):
     iv = os.path.join(d, "emb", "alone")
     from pytorch_kaldi_resnet_amd import kaldi_io, scoring
     emb = scoring.read_embeddings(iv)
+    # the native, length-bucketed reader at batch 8 (text and binary output) must give the same embeddings
+    for fmt in ("text", "fv"):
+        dec2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "decode.py"), "--gpu", "0", "--workers", "2",
+                               "--batch-size", "8", "--chunk-size", "-1", "--spk_num", str(n_spk), "--arch", "resnet34",
+                               "--input-dim", "80", "--pooling", "mean+std", "--model-path", ckpt_path, "--native-reader",
+                               "--out-format", fmt, "--decode-scp", os.path.join(d, "decode.scp"),
+                               "--out-path", os.path.join(d, "emb_" + fmt)], env=env, capture_output=True, text=True, timeout=600)
+        assert dec2.returncode == 0, dec2.stdout[-3000:] + dec2.stderr[-3000:]
+        emb2 = scoring.read_embeddings(os.path.join(d, "emb_" + fmt, "alone"))
+        assert sorted(emb2) == sorted(emb)
+        for k in emb:
+            a, b = np.asarray(emb[k], dtype=np.float64), np.asarray(emb2[k], dtype=np.float64)
+            # batch composition changes which tile/summation order a sample sees only through BN-free eval kernels: identical
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), k
     assert len(emb) == sum(1 for _ in open(os.path.join(d, "decode.scp")))
     # the CPU oracle on the same checkpoint
     from oracle import spk_oracle as O
