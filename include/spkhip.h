@@ -47,14 +47,17 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
  * scripts/train_resnet.py:327).  Logical output pixel (oy,ox) of an OH x OW grid reads input pixel
  * (oy*IS + tap_dy[t], ox*IS + tap_dx[t]) with weight tap tap_w[t] and is stored at (oy*OS + ooy, ox*OS + oox)
  * of the physical [B][OHf][OWf][Cout] output.  TH x TW = pixel region per block (<= 128*MT pixels),
- * MT in 1..4 m-tiles per wave, NT in {1,2,4} 32-channel n-tiles per block.
+ * MT in 1..4 m-tiles per wave, NT in {1,2,4} 32-channel n-tiles per block, kc = 32-channel planes staged per barrier
+ * (1 for 3x3; up to 4 for single-tap 1x1 convolutions; ntaps*kc <= 9, Cin % (32*kc) == 0).  ips = input pixel stride:
+ * the taps address a logical input grid whose pixel (y,x) is physical pixel (y*ips, x*ips) - a strided 1x1 convolution
+ * is run as IS = 1, ips = 2 so that only the pixels it uses are staged.
  * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* bn_raw,
                   const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
-                  int TW, int MT, int NT, int flags, void* stream);
+                  int TW, int MT, int NT, int kc, int ips, int flags, void* stream);
 
 /* Weight gradient of a 3x3 (pad 1) or 1x1 (pad 0) conv at stride 1 or 2 (autograd of nn.Conv2d).
  * x: conv input [B][IH][IW][Cin] (optionally raw + fused BN/ReLU via in_scale/in_shift and SPK_IN_AFFINE_RELU),

@@ -39,7 +39,8 @@ struct ConvArgs {
     const float* bn_act;   //   activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0)
     const float* bn4;      //   [4][Cout]: mean, invstd, scale, shift of that BatchNorm
     float* stats;
-    int B, IH, IW, Cin;
+    int B, IH, IW, Cin;    // IH, IW: logical input grid (= physical / ips, rounded up)
+    int IHp, IWp, ips;     // physical input dims and pixel stride: logical pixel (y,x) lives at (y*ips, x*ips)
     int OH, OW;            // logical output grid
     int OHf, OWf, Cout;    // physical output tensor
     int IS, OS, ooy, oox;
@@ -47,8 +48,11 @@ struct ConvArgs {
     int halo_h, halo_w, min_dy, min_dx;
     unsigned halo_w_magic;   // ceil(2^32 / halo_w): p / halo_w == umulhi(p, magic) for p * halo_w < 2^32
     int ntaps, ncg, nblocks, flags;
-    int tap_off[9];   // LDS offset (float4 units) of the tap inside the halo tile
+    int tap_off[9];   // LDS offset (float4 units) of the (tap, channel plane) inside the staged tile
     int tap_w[9];     // weight tap index
+    int tap_g[9];     // weight K-group offset of the channel plane (4 groups of 8 channels per plane)
+    int kc;           // channel planes (of 32) staged per barrier: > 1 only for single-tap (1x1) convolutions, whose K loop
+                      // per 32-channel chunk is too short to amortise a staging phase
 };
 
 template <int MT, int NT>
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nchunks = a.Cin / CK;
+    const int nchunks = a.Cin / (CK * a.kc);
+    const int plane_floats = a.halo_h * a.halo_w * LPS;
     const int halo_pix = a.halo_h * a.halo_w;
     const int cout32 = a.Cout >> 5;
     const int quad = tid & 7;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         // already in flight, and the next tap's table entries (scalar loads) are fetched a whole tap early, so the
         // matrix pipe never waits on a memory round trip inside a wave.
         const f32x4* lds4 = (const f32x4*)lds;
-        const float* wbase = a.wpk + ((size_t)(ch * 4) * cout32 + cg * NT) * 256 + lane * 4;
+        const float* wbase = a.wpk + ((size_t)(ch * a.kc * 4) * cout32 + cg * NT) * 256 + lane * 4;
         const size_t tap_stride = (size_t)(a.Cin >> 3) * cout32 * 256;
         const size_t grp_stride = (size_t)cout32 * 256;
         auto load_b = [&](f32x4* bf, int tw, int g) {
@@ -149,12 +154,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int j = 0; j < NT; ++j) bq[g][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
         for (int i = 0; i < MT; ++i) a0[i] = a1[i] = (f32x4){1.f, 2.f, 3.f, 4.f};
 #endif
-        int tw = a.tap_w[0], toff = a.tap_off[0];
+        int tw = a.tap_w[0], toff = a.tap_off[0], tg = a.tap_g[0];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) load_b(bq[g], tw, g);
+        for (int g = 0; g < 4; ++g) load_b(bq[g], tw, tg + g);
         __syncthreads();  // every wave is done reading the previous chunk's tile
-        {
-            const int c = ch * CK + quad * 4;
+        for (int pl = 0; pl < a.kc; ++pl) {
+            const int c = (ch * a.kc + pl) * CK + quad * 4;
+            float* ldsp = lds + pl * plane_floats;
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
             if (flags & SPK_IN_AFFINE_RELU) {
                 sc = *(const f32x4*)(a.in_scale + c);
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     const int iy = iy0 + hy, ix = ix0 + hx;
                     inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
                     const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                    v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c);
+                    v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IHp + cy * a.ips) * a.IWp + cx * a.ips) * a.Cin + c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         w[3] = fmaxf(w[3], 0.f);
                     }
                     if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (p < halo_pix) *(f32x4*)(lds + p * LPS + quad * 4) = w;
+                    if (p < halo_pix) *(f32x4*)(ldsp + p * LPS + quad * 4) = w;
                 }
             }
         }
@@ -204,33 +210,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             // the prefetches below are unconditional (the last tap re-fetches itself) so that the loop body is
             // branch-free and the compiler can emit counted vmcnt waits instead of vmcnt(0) at every tap
             const int tn = t + 1 < a.ntaps ? t + 1 : t;
-            const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn];
+            const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn], tg_n = a.tap_g[tn];
             // group 0
             load_a(a1, toff, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, bq[0]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(bq[0], tw_n, 0);
+            load_b(bq[0], tw_n, tg_n + 0);
             // group 1
             load_a(a0, toff, 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, bq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(bq[1], tw_n, 1);
+            load_b(bq[1], tw_n, tg_n + 1);
             // group 2
             load_a(a1, toff, 3);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, bq[2]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(bq[2], tw_n, 2);
+            load_b(bq[2], tw_n, tg_n + 2);
             // group 3
             load_a(a0, toff_n, 0);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, bq[3]);
             __builtin_amdgcn_sched_barrier(0);
-            load_b(bq[3], tw_n, 3);
+            load_b(bq[3], tw_n, tg_n + 3);
             tw = tw_n;
             toff = toff_n;
+            tg = tg_n;
         }
     }
 
@@ -340,12 +347,13 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
                              float* stats, int B, int IH, int IW, int Cin, int OH,
                              int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
                              const int* tap_dy, const int* tap_dx, const int* tap_w, int TH, int TW, int MT,
-                             int NT, int flags, void* stream) {
+                             int NT, int kc, int ips, int flags, void* stream) {
     SPK_REQUIRE(in && wpk && out, "spk_conv_mfma: null pointer");
     SPK_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "spk_conv_mfma: empty tensor");
     SPK_REQUIRE(Cin % 32 == 0 && Cin > 0, "spk_conv_mfma: Cin=%d must be a multiple of 32", Cin);
     SPK_REQUIRE(NT >= 1 && Cout % (32 * NT) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT (NT=%d)", Cout, NT);
     SPK_REQUIRE(ntaps >= 1 && ntaps <= 9, "spk_conv_mfma: ntaps=%d out of range", ntaps);
+    SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (32 * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
     SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT, "spk_conv_mfma: tile %dx%d exceeds 128*MT (MT=%d)", TH, TW, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
     SPK_REQUIRE((OH - 1) * OS + ooy < OHf && (OW - 1) * OS + oox < OWf, "spk_conv_mfma: logical grid exceeds the output tensor");
@@ -361,7 +369,8 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.in = in; a.wpk = wpk; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift;
     a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;
     a.bn_raw = bn_raw; a.bn_act = bn_act; a.bn4 = bn4;
-    a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
+    SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);
+    a.B = B; a.IHp = IH; a.IWp = IW; a.ips = ips; a.IH = (IH + ips - 1) / ips; a.IW = (IW + ips - 1) / ips; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
     a.IS = IS; a.OS = OS; a.ooy = ooy; a.oox = oox; a.TH = TH; a.TW = TW;
     a.tiles_y = spk_ceil_div(OH, TH); a.tiles_x = spk_ceil_div(OW, TW);
     int mindy = 127, mindx = 127, maxdy = -127, maxdx = -127;
@@ -377,12 +386,26 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.min_dy = mindy; a.min_dx = mindx;
     a.halo_h = (TH - 1) * IS + (maxdy - mindy) + 1;
     a.halo_w = (TW - 1) * IS + (maxdx - mindx) + 1;
-    for (int t = 0; t < ntaps; ++t) a.tap_off[t] = ((tap_dy[t] - mindy) * a.halo_w + (tap_dx[t] - mindx)) * (LPS / 4);
+    a.kc = kc;
+    {   // expand (spatial tap) x (channel plane): plane-major, so one plane's taps are consecutive
+        int sp_off[9], sp_w[9];
+        for (int t = 0; t < ntaps; ++t) {
+            sp_off[t] = ((tap_dy[t] - mindy) * a.halo_w + (tap_dx[t] - mindx)) * (LPS / 4);
+            sp_w[t] = tap_w[t];
+        }
+        const int plane4 = a.halo_h * a.halo_w * (LPS / 4);
+        for (int tt = 0; tt < ntaps * kc; ++tt) {
+            const int t = tt % ntaps, pl = tt / ntaps;
+            a.tap_off[tt] = sp_off[t] + pl * plane4;
+            a.tap_w[tt] = sp_w[t];
+            a.tap_g[tt] = pl * 4;
+        }
+    }
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
-    a.ntaps = ntaps; a.ncg = Cout / (32 * NT);
+    a.ntaps = ntaps * kc; a.ncg = Cout / (32 * NT);
     a.nblocks = B * a.tiles_y * a.tiles_x * a.ncg;
     a.flags = flags;
-    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * LPS * sizeof(float);
+    size_t lds_bytes = (size_t)kc * a.halo_h * a.halo_w * LPS * sizeof(float);
     const size_t red_bytes = (size_t)4 * 32 * (NT * 32 + 4) * sizeof(float);   // epilogue transpose slabs, one per wave
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);

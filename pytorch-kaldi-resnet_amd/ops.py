@@ -53,10 +53,21 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     dys = [t[0] for t in taps]
     dxs = [t[1] for t in taps]
     tws = [t[2] for t in taps]
+    ips = 1
+    if len(taps) == 1 and IS > 1 and dys[0] == 0 and dxs[0] == 0:
+        ips, IS = IS, 1          # strided 1x1: address the input through a strided view, stage only the pixels used
     key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
     if tiling.AUTOTUNE and key not in tiling.FORCE_CONV and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu)
     TH, TW, MT, NT = tiling.conv_tile(*key)
+    # single-tap (1x1) convolutions stage several 32-channel planes per barrier: their K loop per plane is only 4 MFMA groups
+    kc = 1
+    if len(taps) == 1:
+        halo = ((TH - 1) * IS + 1) * ((TW - 1) * IS + 1)
+        for cand in (4, 2):
+            if Cin % (32 * cand) == 0 and cand * halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD:
+                kc = cand
+                break
     flags = 0
     if in_affine is not None:
         flags |= IN_AFFINE_RELU
@@ -81,7 +92,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
          ptr(epi_add), ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
-         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, flags, stream(),
+         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, stream(),
          label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
 
