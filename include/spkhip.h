@@ -32,6 +32,10 @@ const char* spk_last_error(void);
 #define SPK_EPI_ADD 4        /* out += epi_add[same index]              (residual add / gradient accumulation) */
 #define SPK_EPI_RELU 8       /* out = max(out, 0) */
 #define SPK_EPI_STATS 16     /* stats[4*pixel_tile + wave][c] = (sum, sumsq) of the stored values (train-mode BN) */
+#define SPK_IN_BNBWD 64      /* stride-1 data gradients: the staged input is BatchNorm-backward(in) computed on the fly from
+                                in, in_raw, the mask (in_act > 0, or in_raw*scale+shift > 0 when in_act is NULL), in_bn4
+                                [mean,invstd,scale,shift][Cin] and in_coef [3][Cin] (spk_bn_bwd_finalize); the tile owner
+                                writes that value to side_draw (for the weight gradient) and in*mask to side_dz (optional) */
 #define SPK_EPI_BNBWD 32     /* with EPI_STATS, data-gradient launches: stats = (sum dz, sum dz*xhat) of the BatchNorm whose
                                 output gradient this launch produces (dz = out * mask; mask = bn_act > 0, or
                                 bn_raw*scale+shift > 0 when bn_act is NULL; bn4 = [mean, invstd, scale, shift][Cout]) */
@@ -53,8 +57,9 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
  * is run as IS = 1, ips = 2 so that only the pixels it uses are staged.
  * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
-                  const float* epi_scale, const float* epi_shift, const float* epi_add, const float* bn_raw,
-                  const float* bn_act, const float* bn4, float* stats, int B, int IH,
+                  const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
+                  const float* in_act, const float* in_bn4, const float* in_coef, float* side_draw, float* side_dz,
+                  const float* bn_raw, const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
                   int TW, int MT, int NT, int kc, int ips, int flags, void* stream);

@@ -35,6 +35,12 @@ struct ConvArgs {
     const float* epi_scale;
     const float* epi_shift;
     const float* epi_add;
+    const float* in_raw;   // SPK_IN_BNBWD: the staged input is BatchNorm-backward(in): raw conv output of that BatchNorm,
+    const float* in_act;   //   its activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0),
+    const float* in_bn4;   //   [4][Cin]: mean, invstd, scale, shift,
+    const float* in_coef;  //   [3][Cin]: gamma*invstd, mean(dz), mean(dz*xhat)  (spk_bn_bwd_finalize)
+    float* side_draw;      //   optional side outputs of the tile's own pixels: the transformed value (gradient wrt the raw
+    float* side_dz;        //   conv output, consumed by the weight gradient) and dz = in*mask (the shortcut gradient)
     const float* bn_raw;   // SPK_EPI_BNBWD: raw conv output of the BatchNorm whose backward statistics are reduced here
     const float* bn_act;   //   activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0)
     const float* bn4;      //   [4][Cout]: mean, invstd, scale, shift of that BatchNorm
@@ -55,7 +61,7 @@ struct ConvArgs {
                       // per 32-channel chunk is too short to amortise a staging phase
 };
 
-template <int MT, int NT>
+template <int MT, int NT, bool BNBWD>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -166,40 +172,91 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 sc = *(const f32x4*)(a.in_scale + c);
                 sh = *(const f32x4*)(a.in_shift + c);
             }
-            // U independent 16-byte loads in flight per thread (addresses clamped, zero selected afterwards: no branch
-            // around a load, so the compiler issues the whole batch before the first wait)
-            constexpr int U = STAGE_U;
-#ifdef ABL_NO_STAGE
-            for (int base = tid >> 3; base < 0; base += 32 * U) {
-#else
-            for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
-#endif
-                f32x4 v[U];
-                bool inb[U];
+            if constexpr (BNBWD) {
+                // The input of this data gradient is BatchNorm-backward of `in`:
+                //     dz = in * mask,  xhat = (raw - mean)*invstd,  value = k1*(dz - m1 - xhat*m2)
+                // computed while staging, so the separate apply pass over the tensor (and its re-read here) disappears.
+                // The block that owns the tile (cout group 0) also writes the values of its own pixels back to memory
+                // for the weight gradient, and dz for the shortcut path.
+                const f32x4 mu = *(const f32x4*)(a.in_bn4 + c), is = *(const f32x4*)(a.in_bn4 + a.Cin + c);
+                const f32x4 bsc = *(const f32x4*)(a.in_bn4 + 2 * a.Cin + c), bsh = *(const f32x4*)(a.in_bn4 + 3 * a.Cin + c);
+                const f32x4 k1 = *(const f32x4*)(a.in_coef + c), m1 = *(const f32x4*)(a.in_coef + a.Cin + c);
+                const f32x4 m2 = *(const f32x4*)(a.in_coef + 2 * a.Cin + c);
+                const bool owner = (cg == 0);
+                constexpr int U2 = 2;
+                for (int base = tid >> 3; base < halo_pix; base += 32 * U2) {
+                    f32x4 v[U2], rw[U2], ac[U2];
+                    bool inb[U2], core[U2];
+                    size_t off[U2];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int p = base + 32 * u;
-                    p = p < halo_pix ? p : halo_pix - 1;
-                    const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
-                    const int hx = p - hy * a.halo_w;
-                    const int iy = iy0 + hy, ix = ix0 + hx;
-                    inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-                    const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                    v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IHp + cy * a.ips) * a.IWp + cx * a.ips) * a.Cin + c);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int p = base + 32 * u;
-                    f32x4 w = v[u];
-                    if (flags & SPK_IN_AFFINE_RELU) {
-                        w = w * sc + sh;
-                        w[0] = fmaxf(w[0], 0.f);
-                        w[1] = fmaxf(w[1], 0.f);
-                        w[2] = fmaxf(w[2], 0.f);
-                        w[3] = fmaxf(w[3], 0.f);
+                    for (int u = 0; u < U2; ++u) {
+                        int p = base + 32 * u;
+                        p = p < halo_pix ? p : halo_pix - 1;
+                        const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                        const int hx = p - hy * a.halo_w;
+                        const int iy = iy0 + hy, ix = ix0 + hx;
+                        inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                        core[u] = inb[u] && iy >= oy0 && iy < oy0 + a.TH && ix >= ox0 && ix < ox0 + a.TW;
+                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                        off[u] = (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c;
+                        v[u] = *(const f32x4*)(a.in + off[u]);
+                        rw[u] = *(const f32x4*)(a.in_raw + off[u]);
+                        if (a.in_act) ac[u] = *(const f32x4*)(a.in_act + off[u]);
                     }
-                    if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (p < halo_pix) *(f32x4*)(ldsp + p * LPS + quad * 4) = w;
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int p = base + 32 * u;
+                        const f32x4 m = a.in_act ? ac[u] : rw[u] * bsc + bsh;
+                        f32x4 dz;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[u][k] : 0.f;
+                        f32x4 w = k1 * (dz - m1 - ((rw[u] - mu) * is) * m2);
+                        if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (p < halo_pix) {
+                            *(f32x4*)(ldsp + p * LPS + quad * 4) = w;
+                            if (owner && core[u]) {
+                                *(f32x4*)(a.side_draw + off[u]) = w;
+                                if (a.side_dz) *(f32x4*)(a.side_dz + off[u]) = dz;
+                            }
+                        }
+                    }
+                }
+            } else {
+            // U independent 16-byte loads in flight per thread (addresses clamped, zero selected afterwards: no branch
+                // around a load, so the compiler issues the whole batch before the first wait)
+                constexpr int U = STAGE_U;
+#ifdef ABL_NO_STAGE
+                for (int base = tid >> 3; base < 0; base += 32 * U) {
+#else
+                for (int base = tid >> 3; base < halo_pix; base += 32 * U) {
+#endif
+                    f32x4 v[U];
+                    bool inb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int p = base + 32 * u;
+                        p = p < halo_pix ? p : halo_pix - 1;
+                        const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                        const int hx = p - hy * a.halo_w;
+                        const int iy = iy0 + hy, ix = ix0 + hx;
+                        inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                        v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IHp + cy * a.ips) * a.IWp + cx * a.ips) * a.Cin + c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int p = base + 32 * u;
+                        f32x4 w = v[u];
+                        if (flags & SPK_IN_AFFINE_RELU) {
+                            w = w * sc + sh;
+                            w[0] = fmaxf(w[0], 0.f);
+                            w[1] = fmaxf(w[1], 0.f);
+                            w[2] = fmaxf(w[2], 0.f);
+                            w[3] = fmaxf(w[3], 0.f);
+                        }
+                        if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (p < halo_pix) *(f32x4*)(ldsp + p * LPS + quad * 4) = w;
+                    }
                 }
             }
         }
@@ -336,15 +393,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
 template <int MT, int NT>
 static int launch_conv(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    // the BatchNorm-backward input mode is a separate instantiation: its staging registers must not cost the plain
+    // kernel an occupancy step
+    if (a.flags & SPK_IN_BNBWD)
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_mfma");
     return 0;
 }
 
 extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale,
                              const float* in_shift, const float* epi_scale, const float* epi_shift,
-                             const float* epi_add, const float* bn_raw, const float* bn_act, const float* bn4,
-                             float* stats, int B, int IH, int IW, int Cin, int OH,
+                             const float* epi_add, const float* in_raw, const float* in_act, const float* in_bn4,
+                             const float* in_coef, float* side_draw, float* side_dz, const float* bn_raw,
+                             const float* bn_act, const float* bn4, float* stats, int B, int IH, int IW, int Cin, int OH,
                              int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
                              const int* tap_dy, const int* tap_dx, const int* tap_w, int TH, int TW, int MT,
                              int NT, int kc, int ips, int flags, void* stream) {
@@ -363,12 +426,17 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(!(flags & SPK_EPI_AFFINE) || (epi_scale && epi_shift), "spk_conv_mfma: EPI_AFFINE needs scale/shift");
     SPK_REQUIRE(!(flags & SPK_EPI_ADD) || epi_add, "spk_conv_mfma: EPI_ADD needs epi_add");
     SPK_REQUIRE(!(flags & SPK_EPI_STATS) || stats, "spk_conv_mfma: EPI_STATS needs a stats buffer");
+    SPK_REQUIRE(!(flags & SPK_IN_BNBWD) || (in_raw && in_bn4 && in_coef && side_draw && !(flags & SPK_IN_AFFINE_RELU)),
+                "spk_conv_mfma: IN_BNBWD needs in_raw, in_bn4, in_coef and side_draw (and excludes IN_AFFINE_RELU)");
+    SPK_REQUIRE(!(flags & SPK_IN_BNBWD) || (IS == 1 && OS == 1 && ips == 1 && OH == IH && OW == IW && OHf == IH && OWf == IW),
+                "spk_conv_mfma: IN_BNBWD is defined for stride-1 data gradients (input and output grids coincide)");
     SPK_REQUIRE(!(flags & SPK_EPI_BNBWD) || ((flags & SPK_EPI_STATS) && bn_raw && bn4),
                 "spk_conv_mfma: EPI_BNBWD needs EPI_STATS, bn_raw and bn4");
     ConvArgs a;
     a.in = in; a.wpk = wpk; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift;
     a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;
     a.bn_raw = bn_raw; a.bn_act = bn_act; a.bn4 = bn4;
+    a.in_raw = in_raw; a.in_act = in_act; a.in_bn4 = in_bn4; a.in_coef = in_coef; a.side_draw = side_draw; a.side_dz = side_dz;
     SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);
     a.B = B; a.IHp = IH; a.IWp = IW; a.ips = ips; a.IH = (IH + ips - 1) / ips; a.IW = (IW + ips - 1) / ips; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
     a.IS = IS; a.OS = OS; a.ooy = ooy; a.oox = oox; a.TH = TH; a.TW = TW;

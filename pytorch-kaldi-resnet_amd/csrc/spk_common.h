@@ -31,7 +31,8 @@ enum {
     SPK_EPI_ADD = 4,          // v += epi_add[same address as out]
     SPK_EPI_RELU = 8,         // v = max(v, 0)
     SPK_EPI_STATS = 16,       // per-wave per-channel (sum, sumsq) of the stored values
-    SPK_EPI_BNBWD = 32        // with EPI_STATS: (sum dz, sum dz*xhat) of the BatchNorm the output is a gradient of
+    SPK_EPI_BNBWD = 32,       // with EPI_STATS: (sum dz, sum dz*xhat) of the BatchNorm the output is a gradient of
+    SPK_IN_BNBWD = 64         // the staged input is BatchNorm-backward(in) computed on the fly (stride-1 data gradients)
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -102,6 +102,8 @@ class Engine:
         self.use_side_stream = True
         # BatchNorm-backward reductions come out of the producing data-gradient epilogue (EPI_BNBWD) where possible
         self.fuse_bn_reduce = True
+        # ... and the BatchNorm-backward apply runs inside the stride-1 data gradients' input staging (IN_BNBWD)
+        self.fuse_bn_apply = True
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def _all_convs(self):
@@ -334,44 +336,62 @@ class Engine:
                 on_stage_done("stem")
 
     def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None):
-        """-> (gradient wrt the block input, BN-backward partial sums of it or None)."""
+        """Backward of one residual block.  -> (gradient wrt the block input, BN-backward partial sums of it or None).
+
+        Walks the convs last to first.  `g` is the gradient wrt the OUTPUT of bn_i (+ReLU): dout for the last BN (mask
+        = block output > 0), the data gradient of conv_{i+1} for the inner ones (mask recomputed from raw_i).  For a
+        stride-1 conv_i the BatchNorm backward of bn_i is applied inside the data-gradient kernel's input staging
+        (IN_BNBWD): no separate apply pass; the kernel writes draw_i (for the weight gradient) and, for the last BN,
+        dz (the shortcut gradient) as side products.  Stride-2 convs (parity-class launches) keep the separate pass."""
         x, raws, out = rec["x"], rec["raws"], rec["out"]
         n = len(b.convs)
-        # last BN (+ residual + relu): dz is written over dout and is the shortcut gradient
-        bn = b.bns[n - 1]
-        draw = ops.bn_backward(dout, raws[n - 1], out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
-                               dz_out=dout, accumulate=acc, partial=dout_partial)
-        dz = dout
-        for i in range(n - 1, 0, -1):
-            c, pbn = b.convs[i], b.bns[i - 1]
-            # conv i consumed relu(bn_{i-1}(raw_{i-1})) through its fused input transform
-            self._wgrad(raws[i - 1], draw, c.h.weight.grad, c.k, c.stride, in_affine=(pbn.t4[2], pbn.t4[3]),
-                        accumulate=acc)
-            hw = (raws[i - 1].shape[1], raws[i - 1].shape[2])
-            if c.stride == 1 and self.fuse_bn_reduce:
-                # dgrad epilogue also reduces (sum dz, sum dz*xhat) of bn_{i-1}: no separate pass over da / raw
-                da, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, 1, hw, bn_bwd=(raws[i - 1], None, pbn.t4))
+        g, g_part, dz = dout, dout_partial, None
+        for i in range(n - 1, -1, -1):
+            c, bn, raw = b.convs[i], b.bns[i], raws[i]
+            last = i == n - 1
+            inp = x if i == 0 else raws[i - 1]
+            in_aff = None if i == 0 else (b.bns[i - 1].t4[2], b.bns[i - 1].t4[3])
+            hw = (inp.shape[1], inp.shape[2])
+            act = out if last else None
+            # what this conv's data gradient must also do in its epilogue
+            add_dz, bnb = False, None
+            if i > 0:
+                if c.stride == 1 and self.fuse_bn_reduce:
+                    bnb = (raws[i - 1], None, b.bns[i - 1].t4)        # statistics of bn_{i-1}'s backward
+            elif b.ds is None:
+                add_dz = True                                           # identity shortcut: dx = dgrad + dz
+                if c.stride == 1 and self.fuse_bn_reduce and prev is not None:
+                    bnb = (prev[0], x, prev[1])                         # statistics for the previous block's last BN
+            if self.fuse_bn_apply and c.stride == 1:
+                if g_part is None:
+                    g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
+                coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,
+                                       bn.h.bias.grad, acc)
+                draw = torch.empty_like(raw)
+                dzb = torch.empty_like(raw) if last else None
+                res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
+                                     in_bnbwd=(raw, act, bn.t4, coef), side=(draw, dzb))
+                if last:
+                    dz = dzb
             else:
-                da, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw), None
-            draw = ops.bn_backward(da, raws[i - 1], None, pbn.t4, pbn.h.weight.data, pbn.h.weight.grad, pbn.h.bias.grad,
-                                   MASK_RAW, draw_out=da, accumulate=acc, partial=part)
-        c = b.convs[0]
-        self._wgrad(x, draw, c.h.weight.grad, c.k, c.stride, accumulate=acc)
-        part = None
-        if b.ds is None:
-            if c.stride == 1 and self.fuse_bn_reduce and prev is not None:
-                # x is the previous block's relu(bn(raw) + shortcut) (or the stem's relu(bn(raw0))): mask = x > 0
-                dx, part = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, 1, (x.shape[1], x.shape[2]), add=dz,
-                                          bn_bwd=(prev[0], x, prev[1]))
-            else:
-                dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]), add=dz)
-        else:
-            dx = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, (x.shape[1], x.shape[2]))
+                if last:
+                    draw = ops.bn_backward(g, raw, out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
+                                           dz_out=g, accumulate=acc, partial=g_part)
+                    dz = g                                              # dout now holds dz
+                else:
+                    draw = ops.bn_backward(g, raw, None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_RAW,
+                                           draw_out=g, accumulate=acc, partial=g_part)
+                res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb)
+            g, g_part = res if bnb is not None else (res, None)
+            self._wgrad(inp, draw, c.h.weight.grad, c.k, c.stride, in_affine=in_aff, accumulate=acc)
+        dx, part = g, g_part
+        if b.ds is not None:
             cd, bnd = b.ds
             drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
                                     MASK_NONE, draw_out=dz, accumulate=acc)
             self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
             ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True)
+            part = None
         return dx, part
 
     # ---- fused training step (forward + CE + backward, no autograd graph) --------------------------------------

@@ -8,7 +8,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPK_LIB", os.path.join(_HERE, "libspkhip.so"))   # SPK_LIB: A/B builds of the same ABI
 
-IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16, 32
+IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD, IN_BNBWD = 1, 2, 4, 8, 16, 32, 64
 MASK_NONE, MASK_ACT, MASK_RAW = 0, 1, 2
 
 _P = ctypes.c_void_p
@@ -20,7 +20,7 @@ _IP = ctypes.POINTER(ctypes.c_int)
 
 _SIGS = {
     "spk_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "spk_conv_mfma": [_P] * 12 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 7 + [_P],
+    "spk_conv_mfma": [_P] * 18 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 7 + [_P],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 15 + [_P],
     "spk_conv_wgrad_limits": [_I, _IP, _IP],
     "spk_stem_fwd_blocks": [_I, _I, _I],

@@ -5,7 +5,8 @@ import ctypes
 import torch
 
 from . import hip, tiling
-from .hip import (EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, MASK_ACT, MASK_NONE, MASK_RAW,
+from .hip import (EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
+                  MASK_RAW,
                   call, ptr, stream)
 
 BN_EPS = 1e-5
@@ -47,7 +48,7 @@ def pack_conv_weight(w, transpose=False, out=None):
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
-                 bn_bwd=None):
+                 bn_bwd=None, in_bnbwd=None, side=None):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -78,6 +79,10 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         assert epi_add.shape == out.shape
     if relu:
         flags |= EPI_RELU
+    if in_bnbwd is not None:
+        flags |= IN_BNBWD
+        assert in_affine is None and side is not None and side[0].shape == x.shape
+        assert in_bnbwd[0].shape == x.shape and (in_bnbwd[1] is None or in_bnbwd[1].shape == x.shape)
     stats = None
     if bn_bwd is not None:
         want_stats = True
@@ -90,7 +95,11 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     call("spk_conv_mfma", ptr(x), ptr(wpk), ptr(out),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
-         ptr(epi_add), ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
+         ptr(epi_add),
+         ptr(in_bnbwd[0]) if in_bnbwd else None, ptr(in_bnbwd[1]) if in_bnbwd else None,
+         ptr(in_bnbwd[2]) if in_bnbwd else None, ptr(in_bnbwd[3]) if in_bnbwd else None,
+         ptr(side[0]) if side else None, ptr(side[1]) if side else None,
+         ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, stream(),
          label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
@@ -160,11 +169,15 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
     return out, st
 
 
-def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None):
+def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None, in_bnbwd=None,
+               side=None):
     """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
     `add` (same shape as dx) is summed in the epilogue; accumulate=True adds onto the existing `out`.
     bn_bwd = (raw, act or None, bn4[4][Cin]) (stride-1 only): dx is the gradient wrt the output of that BatchNorm
-    (+ReLU); the launch also returns the BatchNorm-backward partial sums -> (dx, partial)."""
+    (+ReLU); the launch also returns the BatchNorm-backward partial sums -> (dx, partial).
+    in_bnbwd = (raw, act or None, bn4[4][Cout], coef[3][Cout]) + side = (draw_out, dz_out or None) (stride-1 only): `dy` is
+    the gradient wrt a BatchNorm(+ReLU) OUTPUT; the BatchNorm backward is applied while staging and the gradient wrt
+    the raw conv output is also written to draw_out (and dy*mask to dz_out)."""
     B, OH, OW, Cout = dy.shape
     IH, IW = in_hw
     if out is None:
@@ -178,9 +191,10 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             taps = [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
         else:
             taps = [(0, 0, 0)]
-        st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd)
+        st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd, in_bnbwd,
+                          side)
         return (out, st) if bn_bwd is not None else out
-    assert stride == 2 and bn_bwd is None
+    assert stride == 2 and bn_bwd is None and in_bnbwd is None
     if ksize == 1:
         # only even input pixels receive gradient from a strided 1x1 conv
         if not accumulate:
@@ -330,6 +344,26 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
          ptr(draw_out), ptr(dz_out), N, C, mask_mode, stream())
     return draw_out
+
+
+def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False):
+    """BatchNorm-backward finalize only: dgamma, dbeta and the coefficient rows [gamma*invstd, mean(dz), mean(dz*xhat)]."""
+    C = gamma.numel()
+    coef = torch.empty(3, C, device=gamma.device, dtype=torch.float32)
+    call("spk_bn_bwd_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(bn4[1]), ptr(dgamma),
+         ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), stream())
+    return coef
+
+
+def bn_bwd_partial(dy, raw, act, bn4, mask_mode):
+    """Stand-alone reduction (sum dz, sum dz*xhat) when no data-gradient epilogue produced it."""
+    C = raw.shape[-1]
+    N = raw.numel() // C
+    nblk = hip.lib().spk_bn_stats_blocks(N, C)
+    part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
+    call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
+         N, C, mask_mode, stream())
+    return part
 
 
 def stats_pool_fwd(x, mode):

@@ -121,6 +121,27 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
             ref0, ref1 = dzr.sum((0, 2, 3)), (dzr * xh).sum((0, 2, 3))
             assert float((tot[:, 0] - ref0).abs().max() / ref0.abs().max()) < 1e-4
             assert float((tot[:, 1] - ref1).abs().max() / ref1.abs().max()) < 1e-4
+    # data gradient whose input is BatchNorm-backward(dy) applied in the staging (IN_BNBWD), with side outputs
+    if s == 1:
+        Co = Cout
+        rawo = rnd(20, B, Co, ref.shape[2], ref.shape[3], scale=2.0, shift=0.3)
+        acto = rnd(21, B, Co, ref.shape[2], ref.shape[3])
+        bn4o = torch.stack([rnd(22, Co, scale=0.3), rnd(23, Co, scale=0.2, shift=1.0), rnd(24, Co, scale=0.5, shift=1.0),
+                            rnd(25, Co, scale=0.4)])
+        coef = torch.stack([rnd(26, Co, scale=0.3, shift=1.0), rnd(27, Co, scale=0.05), rnd(28, Co, scale=0.05)])
+        v4 = lambda t: t.view(1, -1, 1, 1)
+        for act in (None, acto):
+            mask = ((rawo * v4(bn4o[2]) + v4(bn4o[3])) > 0) if act is None else (act > 0)
+            dzr = dy * mask
+            xh = (rawo - v4(bn4o[0])) * v4(bn4o[1])
+            draw_ref = v4(coef[0]) * (dzr - v4(coef[1]) - xh * v4(coef[2]))
+            gx_ref, = torch.autograd.grad(F.conv2d(xr, wr, None, s, pad), [xr], grad_outputs=draw_ref)
+            sd, sz = torch.zeros(B, ref.shape[2], ref.shape[3], Co, device="cuda"), torch.zeros(B, ref.shape[2], ref.shape[3], Co, device="cuda")
+            dxf = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt),
+                                 in_bnbwd=(nhwc(rawo), None if act is None else nhwc(act), bn4o.cuda(), coef.cuda()), side=(sd, sz))
+            assert relerr(nchw(dxf), gx_ref + addt) < 3e-5, "dgrad IN_BNBWD"
+            assert relerr(nchw(sd), draw_ref) < 1e-5, "side draw"
+            assert relerr(nchw(sz), dzr) == 0.0, "side dz"
     # weight gradient (plain and with the fused input transform)
     dw = torch.empty(Cout, Cin, k, k, device="cuda")
     ops.conv_wgrad(xg, nhwc(dy), dw, k, s)
