@@ -104,6 +104,8 @@ class Engine:
         self.fuse_bn_reduce = True
         # ... and the BatchNorm-backward apply runs inside the stride-1 data gradients' input staging (IN_BNBWD)
         self.fuse_bn_apply = True
+        import os
+        self.fuse_apply_min_c = int(os.environ.get("SPK_FUSE_APPLY_MINC", "0"))   # experiment knob: skip the fusion below C channels
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def _all_convs(self):
@@ -362,7 +364,7 @@ class Engine:
                 add_dz = True                                           # identity shortcut: dx = dgrad + dz
                 if c.stride == 1 and self.fuse_bn_reduce and prev is not None:
                     bnb = (prev[0], x, prev[1])                         # statistics for the previous block's last BN
-            if self.fuse_bn_apply and c.stride == 1:
+            if self.fuse_bn_apply and c.stride == 1 and c.cout >= self.fuse_apply_min_c:
                 if g_part is None:
                     g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
                 coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,

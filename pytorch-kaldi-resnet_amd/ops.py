@@ -102,7 +102,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, stream(),
-         label="conv_mfma_kernel<%d,%d>" % (MT, NT), flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
+         label="conv_mfma_kernel<%d,%d,%s>" % (MT, NT, "true" if in_bnbwd is not None else "false"),
+         flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
 
 
