@@ -71,6 +71,9 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
  * the kernel's register prefetch window: halo pixels <= *max_halo_pix, TH*TW <= *max_tile_pix (spk_conv_wgrad_limits). */
 int spk_conv_wgrad_limits(int WN, int* max_halo_pix /*host*/, int* max_tile_pix /*host*/);
 size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
+/* spk_conv_wgrad writes nsplit partial slabs [nsplit][k*k][Cin][Cout] (nsplit <= number of pixel regions); spk_wgrad_reduce
+ * sums them in a fixed order into dw (OIHW), optionally accumulating.  (`dw`/`accumulate` of spk_conv_wgrad are unused.) */
+int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate, void* stream);
 int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                    const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,
                    int TH, int TW, int WN, int nsplit, int flags, int accumulate, void* stream);

@@ -274,6 +274,16 @@ extern "C" size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int C
     return (size_t)nsplit * ksize * ksize * Cin * Cout * sizeof(float);
 }
 
+extern "C" int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate,
+                                void* stream) {
+    SPK_REQUIRE(partial && dw && nslab >= 1 && (ksize == 1 || ksize == 3), "spk_wgrad_reduce: bad arguments");
+    const int ntaps = ksize * ksize, total = ntaps * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, partial, dw, nslab,
+                       ntaps, Cin, Cout, accumulate);
+    SPK_LAUNCH_CHECK("spk_wgrad_reduce");
+    return 0;
+}
+
 extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                               const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout,
                               int ksize, int stride, int TH, int TW, int WN, int nsplit, int flags, int accumulate,
@@ -294,7 +304,7 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.S = stride; a.KW = ksize; a.pad = (ksize == 3) ? 1 : 0;
     a.TH = TH; a.TW = TW; a.tiles_y = spk_ceil_div(OH, TH); a.tiles_x = spk_ceil_div(OW, TW);
     a.nregions = B * a.tiles_y * a.tiles_x;
-    if (nsplit > a.nregions) nsplit = a.nregions;
+    SPK_REQUIRE(nsplit <= a.nregions, "spk_conv_wgrad: nsplit=%d exceeds the %d pixel regions", nsplit, a.nregions);
     a.nsplit = nsplit;
     a.halo_h = (TH - 1) * stride + ksize; a.halo_w = (TW - 1) * stride + ksize;
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
@@ -321,10 +331,5 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
         else if (WN == 2) rc = launch_wgrad<1, 2, 2>(a, lds_bytes, st);
         else rc = launch_wgrad<1, 1, 4>(a, lds_bytes, st);
     }
-    if (rc) return rc;
-    const int total = ntaps * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, st, partial, dw, nsplit, ntaps,
-                       Cin, Cout, accumulate);
-    SPK_LAUNCH_CHECK("spk_wgrad_reduce");
-    return 0;
+    return rc;
 }

@@ -246,15 +246,16 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
         _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
     TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride)
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
-    nsplit = tiling.wgrad_nsplit(nreg, Cin, Cout, WN)
+    nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
     ws = _workspace(nbytes, x.device)
     flags = IN_AFFINE_RELU if in_affine is not None else 0
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, stream(),
-         label="conv_wgrad_kernel<%d,%d,%d>+reduce" % (ksize * ksize, 4 // WN, WN),
+         label="conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
+    call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw
 
 
