@@ -39,6 +39,13 @@ def parse():
     ap.add_argument("--mode", choices=["train", "predict"], default="train",
                     help="train = the BASELINE metric (default); predict = eval-mode embedding extraction (decode.py path)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--arch", choices=["resnet34", "resnet101"], default="resnet34",
+                    help="resnet101 + --speakers 5994 + --frames-range 200 400 = BASELINE configs[3] (parity/coverage case, not the headline)")
+    ap.add_argument("--speakers", type=int, default=SPK)
+    ap.add_argument("--frames-range", type=int, nargs=2, metavar=("LO", "HI"), default=None,
+                    help="one chunk length per step, uniform in [LO, HI] (seeded) like the reference's variable-length "
+                         "batches (scripts/datasets.py:178-193); implies eager launches")
+    ap.add_argument("--autotune", action="store_true", help="time candidate tiles on first use of a launch shape (SPK_AUTOTUNE=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -134,8 +141,12 @@ def main():
 
     torch.manual_seed(0)
     import contextlib
+    if args.autotune:
+        from pytorch_kaldi_resnet_amd import tiling
+        tiling.AUTOTUNE = True
+    nspk = args.speakers
     with contextlib.redirect_stdout(sys.stderr):   # the model announces itself like the reference does; keep stdout = 1 JSON line
-        model = NeuralSpeakerModel(SPK, FEAT, "mean+std", "AAM", 0.2, 30, arch="resnet34").to(dev)
+        model = NeuralSpeakerModel(nspk, FEAT, "mean+std", "AAM", 0.2, 30, arch=args.arch).to(dev)
     model.train()
     opt = FlatSGD(model, 0.1, momentum=0.9, weight_decay=5e-4, grad_scale=1.0 / world)
     red = GradAllReducer(model)
@@ -143,7 +154,19 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.randn(args.batch, FEAT, args.frames, device=dev, generator=gen)
-    y = torch.randint(0, SPK, (args.batch,), device=dev, generator=gen)
+    y = torch.randint(0, nspk, (args.batch,), device=dev, generator=gen)
+    var_x = None
+    if args.frames_range:
+        # a fixed, seeded schedule of chunk lengths (every rank draws the same length per step, as the reference's
+        # batch sampler does); inputs of each distinct length are generated once and stay resident in HBM
+        import random
+        rng = random.Random(4321)
+        lo, hi = args.frames_range
+        lens = [rng.randint(lo, hi) for _ in range(8)]      # 8 distinct lengths, cycled: --warmup 8 touches each once
+        sched = [lens[i % 8] for i in range(args.warmup + args.steps)]
+        var_x = {t: torch.randn(args.batch, FEAT, t, device=dev, generator=gen) for t in sorted(set(sched))}
+        args.no_graph = True
+    step_no = [0]
     eng = model.engine()
     if os.environ.get("SPK_SIDE_STREAM", "1") == "0":
         eng.use_side_stream = False
@@ -152,7 +175,7 @@ def main():
         model.eval()
 
         def step():
-            return model.predict(x).sum()
+            return model.predict(cur_x()).sum()
     else:
         step = None
 
@@ -169,6 +192,13 @@ def main():
             graphed = None
             torch.cuda.synchronize()
 
+    def cur_x():
+        if var_x is None:
+            return x
+        t = sched[step_no[0] % len(sched)]
+        step_no[0] += 1
+        return var_x[t]
+
     def train_step():
         if graphed is not None and PROFILE_OFF():
             loss, _, _ = graphed(x, y)
@@ -176,7 +206,7 @@ def main():
             opt.step()
             return loss
         opt.zero_grad(set_to_none=True)
-        loss, _, _ = eng.loss_and_grad(x, y, red.on_stage_done if world > 1 else None)
+        loss, _, _ = eng.loss_and_grad(cur_x(), y, red.on_stage_done if world > 1 else None)
         red.finish()
         opt.step()
         return loss
@@ -250,7 +280,8 @@ def main():
                                         "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
+    headline = args.arch == "resnet34" and nspk == SPK and var_x is None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train" and headline:
         log("roofline pass done; timing the CPU oracle (bounded sample)")
         cpu = cpu_baseline(args)
         log("cpu baseline done")
@@ -258,16 +289,20 @@ def main():
         log("embedding parity vs oracle: max 1-cos = %.3e" % parity)
     if rank == 0:
         gb = args.batch * world
+        arch_name = {"resnet34": "ResNet-34", "resnet101": "ResNet-101"}[args.arch]
+        frames_desc = ("%d-frame" % args.frames) if var_x is None else "%d..%d-frame (one length per step)" % tuple(args.frames_range)
         out = {
-            "metric": "utterances/sec (300-frame x 80 fbank, bs256/GPU), ResNet-34 + AAM-softmax training step"
-            if args.mode == "train" else "utterances/sec, eval-mode embedding extraction (predict), ResNet-34",
+            "metric": ("utterances/sec (%s x 80 fbank, bs%d/GPU), %s + AAM-softmax training step" % (frames_desc, args.batch, arch_name))
+            if args.mode == "train" else "utterances/sec, eval-mode embedding extraction (predict), %s" % arch_name,
             "value": round(gb * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ResNet-34 + AAM-softmax (m 0.2, s 30), %d speakers, "
-                                   "%d-frame x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
-                                   % (SPK, args.frames, FEAT, args.batch),
-                       "global_batch": gb, "frames": args.frames, "feat_dim": FEAT, "speakers": SPK,
+            "config": {"workload": "%s: %s + AAM-softmax (m 0.2, s 30), %d speakers, "
+                                   "%s x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
+                                   % ("BASELINE configs[1]" if headline else "non-headline case", arch_name, nspk,
+                                      frames_desc, FEAT, args.batch),
+                       "global_batch": gb, "frames": args.frames if var_x is None else list(args.frames_range),
+                       "feat_dim": FEAT, "speakers": nspk,
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed is not None else "eager"},
             "final_loss": round(lossv, 4),
             "roofline": roofline, "cpu_baseline": cpu,

@@ -147,6 +147,18 @@ int spk_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* 
 int spk_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay,
                  float grad_scale, int first_step, void* stream);
 
+/* ---- cosine scoring back end (the step after the path) ----------------- */
+/* out[n] = (emb[n] - mean) / max(||emb[n] - mean||, eps): mean subtraction of scripts/cosine_score.py:52-60 followed by
+ * the normalisation inside F.cosine_similarity (:62, eps 1e-8) / F.normalize (scripts/compute_topk_mean_std.py:13,16) */
+int spk_center_normalize(const float* emb /*[N][D]*/, const float* mean /*[D] or NULL*/, float* out, int N, int D, float eps,
+                         void* stream);
+/* out[t] = <en[ia[t]], te[ib[t]]> over normalised rows: the per-trial loop of scripts/cosine_score.py:57-65 */
+int spk_trial_cosine(const float* en /*[n_en][D]*/, const float* te /*[n_te][D]*/, const int* ia, const int* ib, float* out,
+                     int T, int D, int n_en, int n_te, void* stream);
+/* per row of scores[N][M] (row pitch ld): mean and unbiased std of the k largest entries, M <= 16384
+ * (scripts/compute_topk_mean_std.py:18-21: scores.topk(300), torch.std_mean) */
+int spk_topk_mean_std(const float* scores, float* mean_out, float* std_out, int N, int M, int k, long long ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,12 @@ int spk_ark_probe(int n, const char* const* paths, const int64_t* offsets, int32
 int spk_ark_read_crop(int B, const char* const* paths, const int64_t* data_offsets, const int32_t* rows,
                       const int32_t* starts, int F, int T, float* out, int nthreads);
 void spk_ark_close_all(void);
+/* text-ark embedding writer: out <- "key [ v0 v1 ... ]\n" per row of v[n][D], each value printed exactly as numpy's
+ * str(np.float32) does - the line format of the reference's scripts/decode.py:199-206.  Returns the bytes written
+ * (-1 if cap < spk_text_vectors_bound). */
+int64_t spk_text_vectors_bound(int n, int D, const char* const* keys);
+int64_t spk_format_text_vectors(int n, int D, const float* v, const char* const* keys, char* out, int64_t cap,
+                                int nthreads);
 #ifdef __cplusplus
 }
 #endif

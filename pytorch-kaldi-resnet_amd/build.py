@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspkhip.so")
 SOURCES = ["err.cpp", "conv_mfma.hip", "conv_wgrad.hip", "stem.hip", "bn.hip", "pool.hip", "gemm.hip", "head.hip",
-           "sgd.hip"]
+           "sgd.hip", "score.hip"]
 
 
 def needs_build():
@@ -18,8 +18,11 @@ def needs_build():
         if os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
     io_lib = os.path.join(HERE, "libspkio.so")
-    if not os.path.exists(io_lib) or os.path.getmtime(os.path.join(HERE, "csrc_io", "ark_reader.cpp")) > os.path.getmtime(io_lib):
+    if not os.path.exists(io_lib):
         return True
+    for f in os.listdir(os.path.join(HERE, "csrc_io")):
+        if os.path.getmtime(os.path.join(HERE, "csrc_io", f)) > os.path.getmtime(io_lib):
+            return True
     return False
 
 
@@ -45,7 +48,8 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     # host-only ingest library (no device code)
     subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-shared", "-std=c++17", "-pthread",
-                           os.path.join(HERE, "csrc_io", "ark_reader.cpp"), "-o", os.path.join(HERE, "libspkio.so")])
+                           os.path.join(HERE, "csrc_io", "ark_reader.cpp"), os.path.join(HERE, "csrc_io", "vec_writer.cpp"),
+                           "-o", os.path.join(HERE, "libspkio.so")])
     if verbose:
         print("built", LIB)
     return LIB

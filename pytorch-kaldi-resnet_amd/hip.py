@@ -48,6 +48,9 @@ _SIGS = {
     "spk_mean": [_P, _P, _I, _P],
     "spk_relu_bwd": [_P, _P, _P, _L, _P],
     "spk_sgd_step": [_P, _P, _P, _L, _F, _F, _F, _F, _I, _P],
+    "spk_center_normalize": [_P, _P, _P, _I, _I, _F, _P],
+    "spk_trial_cosine": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "spk_topk_mean_std": [_P, _P, _P, _I, _I, _I, _L, _P],
 }
 
 _lib = None

@@ -31,8 +31,28 @@ def lib():
         l.spk_ark_probe.argtypes = [ctypes.c_int, cpp, i64p, i32p, i32p, i64p]
         l.spk_ark_read_crop.argtypes = [ctypes.c_int, cpp, i64p, i32p, i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_int]
+        l.spk_text_vectors_bound.argtypes = [ctypes.c_int, ctypes.c_int, cpp]
+        l.spk_text_vectors_bound.restype = ctypes.c_int64
+        l.spk_format_text_vectors.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, cpp, ctypes.c_char_p, ctypes.c_int64,
+                                              ctypes.c_int]
+        l.spk_format_text_vectors.restype = ctypes.c_int64
         _LIB = l
     return _LIB
+
+
+def format_text_vectors(keys, vecs, nthreads=4):
+    """bytes of the text ark 'key [ v0 v1 ... ]\\n' per row of float32 vecs [n][D], every value printed exactly like
+    numpy's str(np.float32) (the reference's scripts/decode.py:206 line format), formatted natively on `nthreads` threads."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    n, D = vecs.shape
+    assert len(keys) == n
+    arr = (ctypes.c_char_p * n)(*[k.encode() for k in keys])
+    cap = lib().spk_text_vectors_bound(n, D, arr)
+    buf = ctypes.create_string_buffer(cap)
+    w = lib().spk_format_text_vectors(n, D, vecs.ctypes.data, arr, buf, cap, int(nthreads))
+    if w < 0:
+        raise RuntimeError("spk_format_text_vectors: buffer too small")
+    return buf.raw[:w]
 
 
 def _check(rc, what):

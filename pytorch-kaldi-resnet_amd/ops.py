@@ -60,7 +60,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
     if tiling.AUTOTUNE and key not in tiling.FORCE_CONV and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu)
-    TH, TW, MT, NT = tiling.conv_tile(*key)
+    TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0)
     # single-tap (1x1) convolutions stage several 32-channel planes per barrier: their K loop per plane is only 4 MFMA groups
     kc = 1
     if len(taps) == 1:
@@ -387,7 +387,7 @@ def gemm(A, Bm, M, N, K, sam, sak, sbk, sbn, bias=None, out=None, alpha=1.0, acc
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     call("spk_gemm_f32", ptr(A), ptr(Bm), ptr(out), ptr(bias), M, N, K, sam, sak, sbk, sbn, out.stride(0), float(alpha),
-         1 if accumulate else 0, stream())
+         1 if accumulate else 0, stream(), label="gemm_f32_kernel", flops=2.0 * M * N * K)
     return out
 
 
@@ -467,3 +467,30 @@ def relu_bwd(y, dy):
 def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first):
     call("spk_sgd_step", ptr(p), ptr(g), ptr(buf), p.numel(), float(lr), float(momentum), float(weight_decay),
          float(grad_scale), 1 if first else 0, stream())
+
+
+# ---- scoring back end ---------------------------------------------------------------------------------------------
+def center_normalize(emb, mean=None, eps=1e-8):
+    """rows of emb [N][D] minus mean, scaled to unit length (max(norm, eps))."""
+    N, D = emb.shape
+    out = torch.empty_like(emb)
+    call("spk_center_normalize", ptr(emb), ptr(mean), ptr(out), N, D, float(eps), stream())
+    return out
+
+
+def trial_cosine(en, te, ia, ib):
+    """out[t] = <en[ia[t]], te[ib[t]]>; ia / ib int32 device tensors (validated by the caller)."""
+    T = ia.numel()
+    out = torch.empty(T, device=en.device, dtype=torch.float32)
+    assert ia.dtype == torch.int32 and ib.dtype == torch.int32 and ib.numel() == T and en.shape[1] == te.shape[1]
+    call("spk_trial_cosine", ptr(en), ptr(te), ptr(ia), ptr(ib), ptr(out), T, en.shape[1], en.shape[0], te.shape[0], stream())
+    return out
+
+
+def topk_mean_std(scores, k):
+    """mean / unbiased std of the k largest entries of every row of scores [N][M]."""
+    N, M = scores.shape
+    mean = torch.empty(N, device=scores.device, dtype=torch.float32)
+    std = torch.empty_like(mean)
+    call("spk_topk_mean_std", ptr(scores), ptr(mean), ptr(std), N, M, int(k), scores.stride(0), stream())
+    return mean, std

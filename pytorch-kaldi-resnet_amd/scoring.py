@@ -1,8 +1,10 @@
-"""Cosine scoring back end (the step after the path): global mean, mean-subtracted cosine per trial, EER.
+"""Cosine scoring back end (the step after the path): global mean, mean-subtracted cosine per trial, EER,
+cohort top-k statistics and adaptive S-norm.
 
-Behaviour of the reference's scripts/compute_mean.py:9-33, scripts/cosine_score.py:52-68 and
-scripts/compute_eer.py:35-105 (same file formats, same numbers), vectorised with numpy instead of a
-per-trial Python/torch loop.
+Behaviour of the reference's scripts/compute_mean.py:9-33, scripts/cosine_score.py:52-68,
+scripts/compute_eer.py:35-105, scripts/compute_topk_mean_std.py:10-23 and scripts/adaptive_snorm.py:14-40 (same file
+formats, same numbers).  Two back ends with the same results to fp32 rounding: `host` (numpy, vectorised instead of a
+per-trial Python/torch loop) and `hip` (csrc/score.hip through ops.py: embeddings stay in HBM, one launch per stage).
 """
 import numpy as np
 
@@ -25,7 +27,22 @@ def compute_mean(ark_path, mean_path=None):
     return mean
 
 
-def cosine_score(enroll, test, trials_path, mean=None, score_path=None):
+def _table(vecs, mean):
+    """dict utt -> vector  =>  (key -> row index, float32 [N][D] of mean-subtracted vectors).  The subtraction is done
+    in float64 and cast to float32, as the reference does (numpy float64 ark values minus the mean, then FloatTensor)."""
+    keys = list(vecs)
+    m = np.zeros(1) if mean is None else np.asarray(mean, dtype=np.float64)
+    mat = np.stack([(np.asarray(vecs[k], dtype=np.float64) - m).astype(np.float32) for k in keys])
+    return {k: i for i, k in enumerate(keys)}, mat
+
+
+def _device_rows(mat, eps):
+    import torch
+    from . import ops
+    return ops.center_normalize(torch.from_numpy(np.ascontiguousarray(mat)).cuda(), None, eps)
+
+
+def cosine_score(enroll, test, trials_path, mean=None, score_path=None, backend="host"):
     """scores for '<enroll> <test> target|nontarget' lines; vectors are mean-subtracted in float64, cast to
     float32, cosine = a.b / (max(|a|,eps) * max(|b|,eps)) with eps 1e-8 (F.cosine_similarity)."""
     pairs, labels = [], []
@@ -33,12 +50,24 @@ def cosine_score(enroll, test, trials_path, mean=None, score_path=None):
         a, b, t = line.strip().split()
         pairs.append((a, b))
         labels.append(1 if t == "target" else 0)
-    m = np.zeros(1) if mean is None else np.asarray(mean, dtype=np.float64)
-    ea = np.stack([(np.asarray(enroll[a], dtype=np.float64) - m).astype(np.float32) for a, _ in pairs])
-    tb = np.stack([(np.asarray(test[b], dtype=np.float64) - m).astype(np.float32) for _, b in pairs])
-    num = (ea * tb).sum(1, dtype=np.float32)
-    den = np.maximum(np.linalg.norm(ea, axis=1), 1e-8) * np.maximum(np.linalg.norm(tb, axis=1), 1e-8)
-    scores = (num / den).astype(np.float32)
+    if backend == "hip":
+        import torch
+        from . import ops
+        ie, me = _table(enroll, mean)
+        it, mt = (ie, me) if test is enroll else _table(test, mean)
+        en = _device_rows(me, 1e-8)
+        te = en if test is enroll else _device_rows(mt, 1e-8)
+        ia = torch.tensor([ie[a] for a, _ in pairs], dtype=torch.int32).cuda()    # KeyError = unknown utterance, as on the host
+        ib = torch.tensor([it[b] for _, b in pairs], dtype=torch.int32).cuda()
+        scores = ops.trial_cosine(en, te, ia, ib).cpu().numpy()
+    else:
+        assert backend == "host", backend
+        m = np.zeros(1) if mean is None else np.asarray(mean, dtype=np.float64)
+        ea = np.stack([(np.asarray(enroll[a], dtype=np.float64) - m).astype(np.float32) for a, _ in pairs])
+        tb = np.stack([(np.asarray(test[b], dtype=np.float64) - m).astype(np.float32) for _, b in pairs])
+        num = (ea * tb).sum(1, dtype=np.float32)
+        den = np.maximum(np.linalg.norm(ea, axis=1), 1e-8) * np.maximum(np.linalg.norm(tb, axis=1), 1e-8)
+        scores = (num / den).astype(np.float32)
     if score_path:
         with open(score_path, "w") as f:
             for (a, b), s in zip(pairs, scores):
@@ -54,3 +83,55 @@ def compute_eer(scores, labels):
     fprs = 1.0 - np.cumsum(1.0 - lab) / (len(lab) - lab.sum())
     i = int(np.nanargmin(np.abs(fnrs - fprs)))
     return float(max(fprs[i], fnrs[i]))
+
+
+def topk_mean_std(vecs, cohort, mean=None, topk=300, backend="host"):
+    """utt -> (mean, std) of the `topk` largest cosine scores of the utterance against the cohort vectors
+    (compute_topk_mean_std.py:10-23: both sides mean-subtracted and L2-normalised, unbiased std)."""
+    iv, mv = _table(vecs, mean)
+    _, mc = _table(cohort, mean)
+    if topk > len(mc):
+        raise RuntimeError("selected index k out of range: topk=%d > %d cohort vectors" % (topk, len(mc)))
+    if backend == "hip":
+        from . import ops
+        v, c = _device_rows(mv, 1e-12), _device_rows(mc, 1e-12)
+        scores = ops.gemm(v, c, v.shape[0], c.shape[0], v.shape[1], v.stride(0), 1, 1, c.stride(0))
+        mu, sd = ops.topk_mean_std(scores, topk)
+        mu, sd = mu.cpu().numpy(), sd.cpu().numpy()
+    else:
+        assert backend == "host", backend
+        v = mv / np.maximum(np.linalg.norm(mv, axis=1, keepdims=True), 1e-12)
+        c = mc / np.maximum(np.linalg.norm(mc, axis=1, keepdims=True), 1e-12)
+        top = -np.sort(-(v @ c.T), axis=1)[:, :topk]
+        mu = top.mean(axis=1, dtype=np.float32)
+        sd = top.std(axis=1, ddof=1, dtype=np.float32)
+    return {k: (np.float32(mu[i]), np.float32(sd[i])) for k, i in iv.items()}
+
+
+def write_mean_std(stats, path):
+    with open(path, "w") as f:
+        for k, (m, s) in stats.items():
+            f.write("{} {} {}\n".format(k, m, s))
+
+
+def read_mean_std(path):
+    out = {}
+    for line in open(path):
+        k, m, s = line.strip().split()
+        out[k] = (float(m), float(s))
+    return out
+
+
+def adaptive_snorm(enroll_stats, test_stats, score_in, score_out=None):
+    """adaptive_snorm.py:28-36: half the enrol-side plus half the test-side z-normalised score, in Python floats."""
+    lines, out = [], []
+    for line in open(score_in):
+        a, b, sc = line.strip().split()
+        sc = float(sc)
+        v = (sc - enroll_stats[a][0]) / max(enroll_stats[a][1], 1e-8) / 2 + (sc - test_stats[b][0]) / max(test_stats[b][1], 1e-8) / 2
+        out.append(v)
+        lines.append("{} {} {}".format(a, b, v))
+    if score_out:
+        with open(score_out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return out

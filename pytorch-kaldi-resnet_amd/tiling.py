@@ -78,8 +78,12 @@ def wgrad_candidates(OH, OW, Cin, Cout, ksize, stride, per_config=4):
     return out
 
 
-def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
+def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0):
+    """mode 1 = data gradient with the BatchNorm backward fused into its input staging (heavier staging: it may prefer
+    wider channel tiles); table keys carry the mode as an 8th element and fall back to the plain entry."""
     key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
+    if mode and key + (mode,) in FORCE_CONV:
+        return FORCE_CONV[key + (mode,)]
     if key in FORCE_CONV:
         return FORCE_CONV[key]
     return _conv_tile(*key)

@@ -14,11 +14,14 @@ if __name__ == "__main__":
     ap.add_argument("--test", type=str)
     ap.add_argument("--trials", type=str)
     ap.add_argument("--score-file", type=str)
+    ap.add_argument("--backend", choices=["host", "hip"], default="host", help="hip: normalisation and the trial dot products run on the GPU")
     a = ap.parse_args()
     if not (a.mean and os.path.exists(a.mean)):
         print("mean file missing")
         sys.exit(0)
     mean = kaldi_io.read_vec_flt(a.mean)
     print("loaded mean from {}".format(a.mean))
-    scoring.cosine_score(scoring.read_embeddings(a.enroll), scoring.read_embeddings(a.test), a.trials, mean, a.score_file)
+    en = scoring.read_embeddings(a.enroll)
+    te = en if a.test == a.enroll else scoring.read_embeddings(a.test)
+    scoring.cosine_score(en, te, a.trials, mean, a.score_file, backend=a.backend)
     print("saved scores of {} in {}".format(a.trials, a.score_file))

@@ -8,6 +8,7 @@ utterances are supported: --chunk-size T crops, --chunk-size -1 needs equal leng
 """
 import argparse
 import os
+import time
 import sys
 
 import numpy as np
@@ -88,7 +89,7 @@ def main_worker(gpu, ngpus_per_node, args):
         print("=> no checkpoint found at '{}'".format(args.model_path))
         return
     print("=> loading checkpoint '{}'".format(args.model_path))
-    ckpt = torch.load(args.model_path, map_location="cpu", weights_only=False)
+    ckpt = torch.load(args.model_path, map_location="cpu", weights_only=True)
     model.loadParameters(ckpt["state_dict"])
     print("=> loaded checkpoint '{}' (epoch {})".format(args.model_path, ckpt.get("epoch")))
     model.cuda(args.gpu)
@@ -154,13 +155,50 @@ def native_generator(model, args):
     model.eval()
     name = str(args.gpu) if args.distributed else "alone"
     F = int(table.cols[0])
-    with open(os.path.join(args.out_path, name), "w" if args.out_format == "text" else "wb") as f, torch.no_grad():
-        for b in batches[rank::world]:
-            T = int(T_of[b[0]])
-            buf = torch.empty(len(b), F, T).pin_memory()
-            table.read_crop(b, [0] * len(b), T, buf, max(1, args.workers))
+    mine = batches[rank::world]
+    # three-stage pipeline: a reader thread fills the next pinned batch (pread + transpose in libspkio, GIL released)
+    # and a writer thread formats the previous batch's embeddings (natively, byte-identical to the reference's
+    # str(np.float32) text) while the GPU works on the current one
+    from concurrent.futures import ThreadPoolExecutor
+    from pytorch_kaldi_resnet_amd import ingest, kaldi_io
+    pinned = {}
+
+    def load(n):
+        b = mine[n]
+        T = int(T_of[b[0]])
+        key = (n & 1, len(b), T)
+        buf = pinned.get(key)
+        if buf is None:
+            for k in [k for k in pinned if k[0] == key[0]]:
+                del pinned[k]                    # one live buffer per parity: its previous batch has been consumed
+            buf = pinned[key] = torch.empty(len(b), F, T).pin_memory()
+        table.read_crop(b, [0] * len(b), T, buf, max(1, args.workers))
+        return buf
+
+    def emit(f, keys, pred):
+        if args.out_format == "text":
+            f.write(ingest.format_text_vectors(keys, pred, max(1, args.workers)))
+        else:
+            for i in range(pred.shape[0]):
+                kaldi_io.write_vec_flt(f, np.ascontiguousarray(pred[i]), key=keys[i])
+
+    with open(os.path.join(args.out_path, name), "wb") as f, torch.no_grad(), ThreadPoolExecutor(1) as rd, \
+            ThreadPoolExecutor(1) as wr:
+        nxt = rd.submit(load, 0) if mine else None
+        pending = None
+        t0, done = time.time(), 0
+        for n, b in enumerate(mine):
+            buf = nxt.result()
+            nxt = rd.submit(load, n + 1) if n + 1 < len(mine) else None
             pred = model.predict(buf.cuda(args.gpu, non_blocking=True)).cpu().numpy()
-            _write(f, [utts[k] for k in b], pred, args.out_format)
+            if pending is not None:
+                pending.result()
+            pending = wr.submit(emit, f, [utts[k] for k in b], pred)
+            done += len(b)
+        if pending is not None:
+            pending.result()
+        dt = time.time() - t0
+        print("=> extracted {} utterances in {:.2f} s ({:.0f} utt/s, read + predict + write)".format(done, dt, done / max(dt, 1e-9)))
 
 
 if __name__ == "__main__":

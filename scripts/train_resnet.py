@@ -117,7 +117,7 @@ def main_worker(gpu, ngpus_per_node, args):
     if args.pretrained:
         if os.path.isfile(args.pretrained):
             print("=> using pre-trained model '{}'".format(args.pretrained))
-            ckpt = torch.load(args.pretrained, map_location="cpu", weights_only=False)
+            ckpt = torch.load(args.pretrained, map_location="cpu", weights_only=True)
             model.loadParameters(ckpt["state_dict"])
         else:
             print("=> no pre-trained model found at '{}'".format(args.pretrained))
@@ -135,7 +135,7 @@ def main_worker(gpu, ngpus_per_node, args):
     if args.resume:
         if os.path.isfile(args.resume):
             print("=> loading checkpoint '{}'".format(args.resume))
-            ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+            ckpt = torch.load(args.resume, map_location="cpu", weights_only=True)
             args.start_epoch = ckpt["epoch"]
             best_acc1 = ckpt["best_acc1"]
             model.loadParameters(ckpt["state_dict"])

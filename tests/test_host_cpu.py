@@ -105,6 +105,35 @@ def test_scoring_matches_reference_outputs(gold_dir, tmp_path):
     assert scoring.compute_eer([0.0, 0.1, 0.8, 0.9], [1, 1, 0, 0]) == 1.0
 
 
+def test_adaptive_snorm_matches_reference_outputs(gold_dir, tmp_path):
+    """cohort top-300 statistics and adaptive S-norm against the files written by the reference's own scripts
+    (scripts/compute_topk_mean_std.py, scripts/adaptive_snorm.py; tools/make_golden.py io)."""
+    d = os.path.join(gold_dir, "io")
+    mean = kaldi_io.read_vec_flt(os.path.join(d, "mean.vec"))
+    emb = scoring.read_embeddings(os.path.join(d, "emb.iv"))
+    coh = scoring.read_embeddings(os.path.join(d, "cohort.iv"))
+    assert len(coh) == 320
+    stats = scoring.topk_mean_std(emb, coh, mean, 300)
+    ref = scoring.read_mean_std(os.path.join(d, "topk_mean_std"))
+    assert list(stats) == list(ref)
+    for k in ref:
+        np.testing.assert_allclose(stats[k], ref[k], rtol=2e-6, atol=1e-7)
+    scoring.write_mean_std(stats, str(tmp_path / "ms"))
+    back = scoring.read_mean_std(str(tmp_path / "ms"))
+    assert all(abs(back[k][0] - float(stats[k][0])) < 1e-9 for k in stats)
+    # the S-norm itself is Python-float arithmetic on the three text files: byte-identical output
+    scoring.adaptive_snorm(ref, ref, os.path.join(d, "scores"), str(tmp_path / "snorm"))
+    assert open(str(tmp_path / "snorm")).read() == open(os.path.join(d, "scores_snorm")).read()
+    # the reference's topk(300) raises when the cohort is smaller than k
+    with pytest.raises(RuntimeError):
+        scoring.topk_mean_std(emb, emb, mean, 300)
+    # zero-variance guard of adaptive_snorm.py:33-34 (max(std, 1e-8))
+    flat = {k: (0.0, 0.0) for k in ref}
+    out = scoring.adaptive_snorm(flat, flat, os.path.join(d, "scores"))
+    first = float(open(os.path.join(d, "scores")).readline().split()[2])
+    assert out[0] == first / 1e-8 / 2 + first / 1e-8 / 2
+
+
 def test_datasets_balance_and_crop(gold_dir, tmp_path):
     d = os.path.join(gold_dir, "io")
     u2s = str(tmp_path / "utt2spkid")

@@ -87,3 +87,20 @@ def test_loader_semantics(tmp_path):
         assert any(any(np.array_equal(w, m[s:s + 30]) for s in range(m.shape[0] - 29)) for m in allm if m.shape[0] >= 30)
     with pytest.raises(AssertionError):
         ingest.NativeTrainLoader(scp, u2s, 60, 4)
+
+
+def test_text_vector_writer_is_byte_identical_to_numpy_str():
+    """libspkio's embedding writer against the reference's line format (scripts/decode.py:206:
+    utt + ' [ ' + ' '.join(map(str, row)) + ' ]\\n' with np.float32 elements) over random float32 bit patterns,
+    the positional/scientific switch points, signed zero, denormals and non-finite values."""
+    from pytorch_kaldi_resnet_amd import ingest
+    rs = np.random.RandomState(3)
+    x = rs.randint(0, 2 ** 32, size=(300, 256), dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+    x[0, :14] = [0, -0.0, 1e-4, 9.9999e-5, 1.0001e-4, 1e16, 9.999999e15, 123456789.0, np.nan, np.inf, -np.inf, 1e-5, 1.0, 1e-45]
+    x[1] = rs.randn(256).astype(np.float32)
+    keys = ["spk%03d-utt%d" % (i, i * 7) for i in range(x.shape[0])]
+    ref = "".join(k + " [ " + " ".join(map(str, r)) + " ]\n" for k, r in zip(keys, x))
+    for nthreads in (1, 5):
+        assert ingest.format_text_vectors(keys, x, nthreads).decode() == ref
+    one = ingest.format_text_vectors(["a"], np.array([[1.5]], dtype=np.float32))
+    assert one == b"a [ 1.5 ]\n"

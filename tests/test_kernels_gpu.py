@@ -311,3 +311,50 @@ def test_sgd_matches_oracle(ops):
     ops.sgd_step(p, g2.cuda(), buf, 0.05, 0.9, 5e-4, 1.0, False)
     assert relerr(p.cpu(), st["p"]) < 1e-6
     assert relerr(buf.cpu(), bufs["p"]) < 1e-6
+
+
+def test_scoring_backend_on_device(ops, gold_dir, tmp_path):
+    """csrc/score.hip (normalise, per-trial dot, cohort top-k statistics) against the reference's own score files and
+    against the host back end on a larger random problem."""
+    from pytorch_kaldi_resnet_amd import kaldi_io, scoring
+    d = os.path.join(gold_dir, "io")
+    mean = kaldi_io.read_vec_flt(os.path.join(d, "mean.vec"))
+    emb = scoring.read_embeddings(os.path.join(d, "emb.iv"))
+    coh = scoring.read_embeddings(os.path.join(d, "cohort.iv"))
+    sc, lab = scoring.cosine_score(emb, emb, os.path.join(d, "trials"), mean, str(tmp_path / "scores"), backend="hip")
+    ref = [float(l.split()[2]) for l in open(os.path.join(d, "scores"))]
+    np.testing.assert_allclose(sc, ref, rtol=1e-6, atol=3e-7)
+    assert "{0:.2%}".format(scoring.compute_eer(sc, lab)) == open(os.path.join(d, "eer.txt")).read().strip()
+    st = scoring.topk_mean_std(emb, coh, mean, 300, backend="hip")
+    gold = scoring.read_mean_std(os.path.join(d, "topk_mean_std"))
+    for k in gold:
+        np.testing.assert_allclose(st[k], gold[k], rtol=5e-6, atol=2e-7)
+    # model-sized problem: 256-dim embeddings, 3000 utterances, 1500-vector cohort, 20k trials (two distinct tables)
+    rng = np.random.RandomState(5)
+    spk = rng.randn(60, 256).astype(np.float32)
+    en = {"e%d" % i: spk[i % 60] + 0.8 * rng.randn(256).astype(np.float32) for i in range(3000)}
+    te = {"t%d" % i: spk[i % 60] + 0.8 * rng.randn(256).astype(np.float32) for i in range(2000)}
+    co = {"c%d" % i: rng.randn(256).astype(np.float32) + 0.3 * spk[i % 60] for i in range(1500)}
+    m = rng.randn(256).astype(np.float32) * 0.1
+    tp = str(tmp_path / "trials")
+    with open(tp, "w") as f:
+        for _ in range(20000):
+            a, b = rng.randint(3000), rng.randint(2000)
+            f.write("e%d t%d %s\n" % (a, b, "target" if a % 60 == b % 60 else "nontarget"))
+    s_h, l_h = scoring.cosine_score(en, te, tp, m, backend="host")
+    s_d, l_d = scoring.cosine_score(en, te, tp, m, backend="hip")
+    np.testing.assert_allclose(s_d, s_h, rtol=0, atol=5e-7)
+    assert abs(scoring.compute_eer(s_d, l_d) - scoring.compute_eer(s_h, l_h)) < 1e-3
+    k_h = scoring.topk_mean_std(te, co, m, 300, backend="host")
+    k_d = scoring.topk_mean_std(te, co, m, 300, backend="hip")
+    for k in k_h:
+        np.testing.assert_allclose(k_d[k], k_h[k], rtol=2e-5, atol=5e-7)
+    # k == M, non power-of-two M, duplicate scores
+    x = torch.tensor([[3.0, 1.0, 2.0, 2.0, -1.0], [0.5, 0.5, 0.5, 0.5, 0.5]], device="cuda")
+    mu, sd = ops.topk_mean_std(x, 5)
+    np.testing.assert_allclose(mu.cpu().numpy(), [1.4, 0.5], rtol=1e-6)
+    np.testing.assert_allclose(sd.cpu().numpy(), [np.std([3, 1, 2, 2, -1], ddof=1), 0.0], rtol=1e-6, atol=1e-7)
+    mu, sd = ops.topk_mean_std(x, 2)
+    np.testing.assert_allclose(mu.cpu().numpy(), [2.5, 0.5], rtol=1e-6)
+    with pytest.raises(RuntimeError):
+        ops.topk_mean_std(x, 6)

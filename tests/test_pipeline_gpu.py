@@ -54,7 +54,7 @@ def test_train_decode_score_pipeline(tmp_path):
     # model_best.pth.tar only appears once cv Acc@1 > 0 (reference semantics: is_best = acc1 > best_acc1 = 0)
     ckpt_path = os.path.join(d, "exp", "checkpoint_epoch1.pth.tar")
     assert os.path.exists(ckpt_path) and os.path.exists(os.path.join(d, "exp", "checkpoint_epoch0.pth.tar"))
-    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
     assert set(ckpt) == {"epoch", "arch", "state_dict", "best_acc1", "optimizer"} and len(ckpt["state_dict"]) == 219
     dec = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "decode.py"), "--gpu", "0", "--workers", "0",
                           "--batch-size", "1", "--chunk-size", "-1", "--spk_num", str(n_spk), "--arch", "resnet34",

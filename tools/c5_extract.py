@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""End-to-end extraction + scoring run (case C5) on one GPU box: synthetic ark on local disk ->
+scripts/decode.py --native-reader (bs 512, predict only, text ark) -> compute_mean -> cosine_score --backend hip ->
+compute_eer.  Prints one JSON object with the stage timings; parity of the same pipeline against the CPU oracle is
+tests/test_pipeline_gpu.py."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dir", default="/tmp/c5")
+ap.add_argument("--speakers", type=int, default=200)
+ap.add_argument("--utts-per-speaker", type=int, default=100)
+ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--trials", type=int, default=100000)
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--workers", type=int, default=8)
+ap.add_argument("--out-format", default="text")
+a = ap.parse_args()
+py = sys.executable
+sc = os.path.join(ROOT, "scripts")
+
+
+def run(cmd):
+    t = time.time()
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout)
+        raise SystemExit("failed: %s" % " ".join(cmd))
+    return time.time() - t, r.stdout
+
+
+res = {"utterances": a.speakers * a.utts_per_speaker, "frames": a.frames, "batch": a.batch}
+res["make_data_s"], _ = run([py, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", a.dir, "--speakers", str(a.speakers),
+                             "--utts-per-speaker", str(a.utts_per_speaker), "--min-frames", str(a.frames), "--max-frames",
+                             str(a.frames), "--trials", str(a.trials)])
+import torch  # noqa: E402
+import pytorch_kaldi_resnet_amd  # noqa: E402,F401
+from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel  # noqa: E402
+torch.manual_seed(0)
+m = NeuralSpeakerModel(a.speakers, 80, "mean+std", "AAM", 0.2, 30)
+ck = os.path.join(a.dir, "init.pth.tar")
+torch.save({"epoch": 0, "arch": "resnet34", "state_dict": m.state_dict()}, ck)
+out = os.path.join(a.dir, "emb")
+res["decode_wall_s"], log = run([py, os.path.join(sc, "decode.py"), "--spk_num", str(a.speakers), "--arch", "resnet34",
+                                 "--input-dim", "80", "--pooling", "mean+std", "--model-path", ck, "--decode-scp",
+                                 os.path.join(a.dir, "all.scp"), "--out-path", out, "-b", str(a.batch), "--gpu", "0",
+                                 "--native-reader", "-j", str(a.workers), "--out-format", a.out_format])
+for line in log.splitlines():
+    if line.startswith("=> extracted"):
+        res["decode_loop"] = line
+iv = os.path.join(out, "alone")
+res["embedding_file_mb"] = round(os.path.getsize(iv) / 1e6, 1)
+res["compute_mean_s"], _ = run([py, os.path.join(sc, "compute_mean.py"), iv, os.path.join(a.dir, "mean.vec")])
+res["cosine_score_hip_s"], _ = run([py, os.path.join(sc, "cosine_score.py"), "--mean", os.path.join(a.dir, "mean.vec"), "--enroll", iv,
+                                    "--test", iv, "--trials", os.path.join(a.dir, "trials"), "--score-file",
+                                    os.path.join(a.dir, "scores"), "--backend", "hip"])
+res["cosine_score_host_s"], _ = run([py, os.path.join(sc, "cosine_score.py"), "--mean", os.path.join(a.dir, "mean.vec"), "--enroll", iv,
+                                     "--test", iv, "--trials", os.path.join(a.dir, "trials"), "--score-file",
+                                     os.path.join(a.dir, "scores_host")])
+import numpy as np  # noqa: E402
+s_d = np.array([float(l.split()[2]) for l in open(os.path.join(a.dir, "scores"))])
+s_h = np.array([float(l.split()[2]) for l in open(os.path.join(a.dir, "scores_host"))])
+res["hip_vs_host_max_abs_score_diff"] = float(np.abs(s_d - s_h).max())
+res["compute_eer_s"], eer = run([py, os.path.join(sc, "compute_eer.py"), os.path.join(a.dir, "scores"), os.path.join(a.dir, "trials")])
+res["eer"] = eer.strip().splitlines()[-1]
+_, eer_h = run([py, os.path.join(sc, "compute_eer.py"), os.path.join(a.dir, "scores_host"), os.path.join(a.dir, "trials")])
+res["eer_host_scores"] = eer_h.strip().splitlines()[-1]
+res["trials"] = len(s_d)
+print(json.dumps(res))

@@ -18,6 +18,7 @@ from pytorch_kaldi_resnet_amd import ops, tiling  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--sweep-bnbwd", action="store_true", help="sweep tiles of the stride-1 data gradients in fused BatchNorm-backward mode and merge them into the table")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--feat", type=int, default=80)
@@ -64,6 +65,39 @@ def conv_candidates(OH, OW, IS, ks, Cout):
 
 table = {"conv": {}, "wgrad": {}}
 rows = []
+if args.sweep_bnbwd:
+    table = json.load(open(args.out))
+    for name, Cin, Cout, H, W, k, s in shapes:
+        if k != 3 or s != 1:
+            continue
+        C = Cin
+        dy = torch.randn(B, H, W, C, device=dev)
+        raw, act, raw_p = (torch.randn(B, H, W, C, device=dev) for _ in range(3))
+        draw, dz, dx = (torch.empty(B, H, W, C, device=dev) for _ in range(3))
+        bn4 = torch.randn(4, C, device=dev)
+        coef = torch.randn(3, C, device=dev)
+        wpk_t = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=dev) * 0.05, True)
+        flops = 2.0 * B * H * W * C * C * 9
+        key = (H, W, 1, 3, 3, 9, C)
+        res = []
+        for cand in conv_candidates(H, W, 1, 3, C):
+            tiling.FORCE_CONV[key + (1,)] = cand
+            try:
+                ms = timeit(lambda: ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, W), out=dx, bn_bwd=(raw_p, None, bn4),
+                                                   in_bnbwd=(raw, act, bn4, coef), side=(draw, dz)), args.reps)
+            except RuntimeError:
+                continue
+            res.append((ms, cand))
+        res.sort()
+        tiling.FORCE_CONV[key + (1,)] = res[0][1]
+        table["conv"][",".join(map(str, key + (1,)))] = list(res[0][1])
+        cur = [m for m, c in res if tuple(c) == tuple(tiling.FORCE_CONV.get(key, ()))]
+        print("%-12s bnbwd-dgrad best %s %.3f ms %.1f TF (plain-table tile: %s) | top: %s" % (
+            name, res[0][1], res[0][0], flops / res[0][0] / 1e9, "%.3f ms" % cur[0] if cur else "n/a",
+            " ".join("%s:%.3f" % (c, m) for m, c in res[:6])), flush=True)
+    json.dump(table, open(args.out, "w"), indent=1)
+    print("wrote", args.out)
+    sys.exit(0)
 for name, Cin, Cout, H, W, k, s in shapes:
     x = torch.randn(B, H, W, Cin, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05

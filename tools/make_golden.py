@@ -208,6 +208,22 @@ def record_io():
                                    os.path.join(d, "scores"), os.path.join(d, "trials")],
                                   env=env, cwd=sc, stderr=subprocess.DEVNULL)
     open(os.path.join(d, "eer.txt"), "w").write(eer.decode())
+    # adaptive S-norm (scripts/compute_topk_mean_std.py + scripts/adaptive_snorm.py of the reference): a 320-vector cohort
+    # so that the reference's hard-wired top-300 selection is exercised
+    with open(os.path.join(d, "cohort.iv"), "w") as f:
+        for i in range(320):
+            v = (W.hash_uniform(12, i, 16) * 2 - 1).astype(np.float32)
+            v += (i % 5) * 0.35
+            f.write("coh%03d [ " % i + " ".join(map(str, v)) + " ]\n")
+    subprocess.check_call([sys.executable, os.path.join(sc, "compute_topk_mean_std.py"),
+                           "--mean", os.path.join(d, "mean.vec"), "--ark-file", os.path.join(d, "emb.iv"),
+                           "--cohort-file", os.path.join(d, "cohort.iv"),
+                           "--mean-std-file", os.path.join(d, "topk_mean_std")], env=env, cwd=sc,
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(sc, "adaptive_snorm.py"),
+                           "--enroll", os.path.join(d, "topk_mean_std"), "--test", os.path.join(d, "topk_mean_std"),
+                           "--score-in", os.path.join(d, "scores"), "--score-out", os.path.join(d, "scores_snorm")],
+                          env=env, cwd=sc, stdout=subprocess.DEVNULL)
     # matrices as read back by the reference reader
     mats = {u: kaldi_io.read_mat(l.split()[1].replace("tests/golden/io", d))
             for u, l in zip(utts, lines)}
