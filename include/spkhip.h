@@ -45,6 +45,9 @@ const char* spk_last_error(void);
 /* nn.Conv2d weight [Cout][Cin][KH][KW] (scripts/model.py:12-15,105-110,233-234) -> MFMA fragment order
  * [tap][K/8][N/32][64][4]; transpose = 0 for the forward conv (K = Cin), 1 for its data gradient (K = Cout). */
 int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
+/* the same weights for the bf16-split operand mode of spk_conv_mfma (split = 6 or 9): every weight as three bf16 terms
+ * whose sum is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight */
+int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
 
 /* Implicit-GEMM convolution described by a tap table; replaces F.conv2d forward (scripts/model.py:51,56,
  * 118,122,126,58-59) and, with a transposed pack and mirrored taps, its data gradient (autograd of the same,
@@ -55,14 +58,18 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
  * (1 for 3x3; up to 4 for single-tap 1x1 convolutions; ntaps*kc <= 9, Cin % (32*kc) == 0).  ips = input pixel stride:
  * the taps address a logical input grid whose pixel (y,x) is physical pixel (y*ips, x*ips) - a strided 1x1 convolution
  * is run as IS = 1, ips = 2 so that only the pixels it uses are staged.
- * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave). */
+ * stats (EPI_STATS): [4*B*ceil(OH/TH)*ceil(OW/TW)][Cout][2] floats (one partial row per wave).
+ * split: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (wpk from spk_pack_conv_weight); 6 or 9 = operands split exactly into
+ * three bf16 terms while staged / packed (wpk from spk_pack_conv_weight_split) and the 6 most significant (or all 9) cross
+ * terms multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - inputs, outputs and measured accuracy are fp32
+ * (planes are then 16 channels: Cin % (16*kc) == 0). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
                   const float* in_act, const float* in_bn4, const float* in_coef, float* side_draw, float* side_dz,
                   const float* bn_raw, const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
-                  int TW, int MT, int NT, int kc, int ips, int flags, void* stream);
+                  int TW, int MT, int NT, int kc, int ips, int flags, int split, void* stream);
 
 /* Weight gradient of a 3x3 (pad 1) or 1x1 (pad 0) conv at stride 1 or 2 (autograd of nn.Conv2d).
  * x: conv input [B][IH][IW][Cin] (optionally raw + fused BN/ReLU via in_scale/in_shift and SPK_IN_AFFINE_RELU),

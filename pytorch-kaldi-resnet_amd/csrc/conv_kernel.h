@@ -1,0 +1,489 @@
+#pragma once
+#include "spk_common.h"
+
+#ifndef STAGE_U
+#define STAGE_U 4   // staging loads in flight per thread
+#endif
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// SPLIT == 0: operands stay fp32 (v_mfma_f32_32x32x2_f32).  SPLIT == 6 / 9: every fp32 operand is split into three bf16
+// terms (x = x1 + x2 + x3 exactly: 3 x 8 significand bits) while it is staged (activations) or packed (weights), and the
+// product is formed from the 6 (or all 9) cross terms of weight >= 2^-16 (2^-24) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: measured error against fp64 equals that of the native fp32 matrix instruction
+// (tools/probe/split_probe.hip), at 16/6 of its rate.
+template <int SPLIT>
+struct ConvCfg {
+    static constexpr int CK = SPLIT ? 16 : 32;   // channels per staged plane
+    static constexpr int TPP = CK / 4;           // threads per staged pixel (one float4 of channels each)
+    static constexpr int PPP = 256 / TPP;        // pixels per staging pass of the block
+    // LDS pixel pitch in 16-byte units: fp32 [32 ch + 4 pad] = 144 B; split [3 terms][16 ch bf16] + 16 pad = 112 B.  Both
+    // are odd multiples of 16 B, so the 8 lanes of a ds_read_b128 phase (consecutive pixels) hit distinct bank groups.
+    static constexpr int LP4 = SPLIT ? 7 : 9;
+};
+
+static __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi, float& rlo, float& rhi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;   // round to nearest even
+    rlo = lo - (float)a;                           // exact in fp32
+    rhi = hi - (float)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// w -> three bf16 quads (8 bytes each): w = t0 + t1 + t2
+static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uint2& t2) {
+    float r0, r1, r2, r3, q0, q1, q2, q3;
+    t0.x = pack_bf16x2(w[0], w[1], r0, r1);
+    t0.y = pack_bf16x2(w[2], w[3], r2, r3);
+    t1.x = pack_bf16x2(r0, r1, q0, q1);
+    t1.y = pack_bf16x2(r2, r3, q2, q3);
+    t2.x = pack_bf16x2(q0, q1, r0, r1);
+    t2.y = pack_bf16x2(q2, q3, r2, r3);
+}
+
+struct ConvArgs {
+    const float* in;
+    const float* wpk;
+    float* out;
+    const float* in_scale;
+    const float* in_shift;
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_add;
+    const float* in_raw;   // SPK_IN_BNBWD: the staged input is BatchNorm-backward(in): raw conv output of that BatchNorm,
+    const float* in_act;   //   its activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0),
+    const float* in_bn4;   //   [4][Cin]: mean, invstd, scale, shift,
+    const float* in_coef;  //   [3][Cin]: gamma*invstd, mean(dz), mean(dz*xhat)  (spk_bn_bwd_finalize)
+    float* side_draw;      //   optional side outputs of the tile's own pixels: the transformed value (gradient wrt the raw
+    float* side_dz;        //   conv output, consumed by the weight gradient) and dz = in*mask (the shortcut gradient)
+    const float* bn_raw;   // SPK_EPI_BNBWD: raw conv output of the BatchNorm whose backward statistics are reduced here
+    const float* bn_act;   //   activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0)
+    const float* bn4;      //   [4][Cout]: mean, invstd, scale, shift of that BatchNorm
+    float* stats;
+    int B, IH, IW, Cin;    // IH, IW: logical input grid (= physical / ips, rounded up)
+    int IHp, IWp, ips;     // physical input dims and pixel stride: logical pixel (y,x) lives at (y*ips, x*ips)
+    int OH, OW;            // logical output grid
+    int OHf, OWf, Cout;    // physical output tensor
+    int IS, OS, ooy, oox;
+    int TH, TW, tiles_y, tiles_x;
+    int halo_h, halo_w, min_dy, min_dx;
+    unsigned halo_w_magic;   // ceil(2^32 / halo_w): p / halo_w == umulhi(p, magic) for p * halo_w < 2^32
+    int ntaps, ncg, nblocks, flags;
+    int tap_off[9];   // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
+    int tap_w[9];     // weight tap index
+    int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
+    int kc;           // channel planes (of 32) staged per barrier: > 1 only for single-tap (1x1) convolutions, whose K loop
+                      // per 32-channel chunk is too short to amortise a staging phase
+};
+
+template <int MT, int NT, bool BNBWD, int SPLIT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    using Cfg = ConvCfg<SPLIT>;
+    constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
+    // order (same pixel region, next cout group; then the neighbouring region) share an XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int n = a.nblocks, q = n >> 3, rr = n & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+    }
+    const int cg = bid % a.ncg;
+    const int ptile = bid / a.ncg;
+    int pt = ptile;
+    const int tx = pt % a.tiles_x;
+    pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int b = pt / a.tiles_y;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * a.IS + a.min_dy, ix0 = ox0 * a.IS + a.min_dx;
+    const int npix_tile = a.TH * a.TW;
+    const int n0 = cg * NT * 32;
+    const int flags = a.flags;
+
+    int lbase[MT], obase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int q = (wave * MT + i) * 32 + r;
+        bool v = q < npix_tile;
+        const int qq = v ? q : 0;
+        const int ly = qq / a.TW, lx = qq - ly * a.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        v = v && oy < a.OH && ox < a.OW;
+        lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + h;   // 16-byte units
+        obase[i] = v ? ((b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox) * a.Cout + n0 : -1;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = a.Cin / (CK * a.kc);
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int plane_floats = halo_pix * LP4 * 4;
+    const int cout32 = a.Cout >> 5;
+    const int quad = tid & (TPP - 1);   // this thread's float4 of channels within a staged pixel
+    const int prow = tid / TPP;         // and its pixel slot within a staging pass
+    auto store_px = [&](float* plane, int p, f32x4 w) {
+        if constexpr (SPLIT == 0) {
+            *(f32x4*)(plane + p * (LP4 * 4) + quad * 4) = w;
+        } else {
+            uint2 t0, t1, t2;
+            split3(w, t0, t1, t2);
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][16 ch]: 32 bytes per term
+            dst[0] = t0;
+            dst[4] = t1;
+            dst[8] = t2;
+        }
+    };
+
+    // stage the kc channel planes of chunk `ch` (global -> registers -> fused input transform -> LDS)
+    auto stage_chunk = [&](int ch) {
+        for (int pl = 0; pl < a.kc; ++pl) {
+            const int c = (ch * a.kc + pl) * CK + quad * 4;
+            float* ldsp = lds + pl * plane_floats;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (flags & SPK_IN_AFFINE_RELU) {
+                sc = *(const f32x4*)(a.in_scale + c);
+                sh = *(const f32x4*)(a.in_shift + c);
+            }
+            if constexpr (BNBWD) {
+                // The input of this data gradient is BatchNorm-backward of `in`:
+                //     dz = in * mask,  xhat = (raw - mean)*invstd,  value = k1*(dz - m1 - xhat*m2)
+                // computed while staging, so the separate apply pass over the tensor (and its re-read here) disappears.
+                // The block that owns the tile (cout group 0) also writes the values of its own pixels back to memory
+                // for the weight gradient, and dz for the shortcut path.
+                const f32x4 mu = *(const f32x4*)(a.in_bn4 + c), is = *(const f32x4*)(a.in_bn4 + a.Cin + c);
+                const f32x4 bsc = *(const f32x4*)(a.in_bn4 + 2 * a.Cin + c), bsh = *(const f32x4*)(a.in_bn4 + 3 * a.Cin + c);
+                const f32x4 k1 = *(const f32x4*)(a.in_coef + c), m1 = *(const f32x4*)(a.in_coef + a.Cin + c);
+                const f32x4 m2 = *(const f32x4*)(a.in_coef + 2 * a.Cin + c);
+                const bool owner = (cg == 0);
+                constexpr int U2 = 2;
+                for (int base = prow; base < halo_pix; base += PPP * U2) {
+                    f32x4 v[U2], rw[U2], ac[U2];
+                    bool inb[U2], core[U2];
+                    size_t off[U2];
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        int p = base + PPP * u;
+                        p = p < halo_pix ? p : halo_pix - 1;
+                        const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                        const int hx = p - hy * a.halo_w;
+                        const int iy = iy0 + hy, ix = ix0 + hx;
+                        inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                        core[u] = inb[u] && iy >= oy0 && iy < oy0 + a.TH && ix >= ox0 && ix < ox0 + a.TW;
+                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                        off[u] = (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c;
+                        v[u] = *(const f32x4*)(a.in + off[u]);
+                        rw[u] = *(const f32x4*)(a.in_raw + off[u]);
+                        if (a.in_act) ac[u] = *(const f32x4*)(a.in_act + off[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int p = base + PPP * u;
+                        const f32x4 m = a.in_act ? ac[u] : rw[u] * bsc + bsh;
+                        f32x4 dz;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[u][k] : 0.f;
+                        f32x4 w = k1 * (dz - m1 - ((rw[u] - mu) * is) * m2);
+                        if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (p < halo_pix) {
+                            store_px(ldsp, p, w);
+                            if (owner && core[u]) {
+                                *(f32x4*)(a.side_draw + off[u]) = w;
+                                if (a.side_dz) *(f32x4*)(a.side_dz + off[u]) = dz;
+                            }
+                        }
+                    }
+                }
+            } else {
+            // U independent 16-byte loads in flight per thread (addresses clamped, zero selected afterwards: no branch
+                // around a load, so the compiler issues the whole batch before the first wait)
+                constexpr int U = STAGE_U;
+#ifdef ABL_NO_STAGE
+                for (int base = prow; base < 0; base += PPP * U) {
+#else
+                for (int base = prow; base < halo_pix; base += PPP * U) {
+#endif
+                    f32x4 v[U];
+                    bool inb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int p = base + PPP * u;
+                        p = p < halo_pix ? p : halo_pix - 1;
+                        const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                        const int hx = p - hy * a.halo_w;
+                        const int iy = iy0 + hy, ix = ix0 + hx;
+                        inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                        v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IHp + cy * a.ips) * a.IWp + cx * a.ips) * a.Cin + c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int p = base + PPP * u;
+                        f32x4 w = v[u];
+                        if (flags & SPK_IN_AFFINE_RELU) {
+                            w = w * sc + sh;
+                            w[0] = fmaxf(w[0], 0.f);
+                            w[1] = fmaxf(w[1], 0.f);
+                            w[2] = fmaxf(w[2], 0.f);
+                            w[3] = fmaxf(w[3], 0.f);
+                        }
+                        if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (p < halo_pix) store_px(ldsp, p, w);
+                    }
+                }
+            }
+        }
+    };
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if constexpr (SPLIT == 0) {
+            // K loop over (tap, 8-cin group), software-pipelined one group ahead: while the 4*MT*NT MFMAs of a group
+            // issue (>= 1 k cycles), the B fragments (L2 -> VGPR) and A fragments (LDS -> VGPR) of the next group are
+            // already in flight, and the next tap's table entries (scalar loads) are fetched a whole tap early, so the
+            // matrix pipe never waits on a memory round trip inside a wave.
+            const f32x4* lds4 = (const f32x4*)lds;
+            const float* wbase = a.wpk + ((size_t)(ch * a.kc * 4) * cout32 + cg * NT) * 256 + lane * 4;
+            const size_t tap_stride = (size_t)(a.Cin >> 3) * cout32 * 256;
+            const size_t grp_stride = (size_t)cout32 * 256;
+            auto load_b = [&](f32x4* bf, int tw, int g) {
+                const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
+    #ifdef ABL_NO_BLOAD
+    #pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bf[j]) : "s"(wp));
+    #else
+    #pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = *(const f32x4*)(wp + j * 256);
+    #endif
+            };
+            auto load_a = [&](f32x4* af, int toff4, int g) {
+    #ifdef ABL_NO_ALOAD
+    #pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(af[i]) : "s"(toff4 + g));
+    #else
+    #pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = lds4[lbase[i] + toff4 + g * 2];
+    #endif
+            };
+            auto mma = [&](const f32x4* af, const f32x4* bf) {
+    #pragma unroll
+                for (int s = 0; s < 4; ++s)
+    #pragma unroll
+                    for (int i = 0; i < MT; ++i)
+    #pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            };
+            // B fragments are prefetched a whole tap (4 groups >= 4 k MFMA cycles) ahead into a 4-deep register ring;
+            // A fragments one group ahead (LDS latency is ~100 cycles).
+            f32x4 bq[4][NT], a0[MT], a1[MT];
+    #if defined(ABL_NO_BLOAD) || defined(ABL_NO_ALOAD)
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < NT; ++j) bq[g][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
+            for (int i = 0; i < MT; ++i) a0[i] = a1[i] = (f32x4){1.f, 2.f, 3.f, 4.f};
+    #endif
+            int tw = a.tap_w[0], toff = a.tap_off[0], tg = a.tap_g[0];
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) load_b(bq[g], tw, tg + g);
+            __syncthreads();  // every wave is done reading the previous chunk's tile
+            stage_chunk(ch);
+            __syncthreads();
+
+            load_a(a0, toff, 0);
+            for (int t = 0; t < a.ntaps; ++t) {
+                // the prefetches below are unconditional (the last tap re-fetches itself) so that the loop body is
+                // branch-free and the compiler can emit counted vmcnt waits instead of vmcnt(0) at every tap
+                const int tn = t + 1 < a.ntaps ? t + 1 : t;
+                const int tw_n = a.tap_w[tn], toff_n = a.tap_off[tn], tg_n = a.tap_g[tn];
+                // group 0
+                load_a(a1, toff, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, bq[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(bq[0], tw_n, tg_n + 0);
+                // group 1
+                load_a(a0, toff, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, bq[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(bq[1], tw_n, tg_n + 1);
+                // group 2
+                load_a(a1, toff, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, bq[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(bq[2], tw_n, tg_n + 2);
+                // group 3
+                load_a(a0, toff_n, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, bq[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(bq[3], tw_n, tg_n + 3);
+                tw = tw_n;
+                toff = toff_n;
+                tg = tg_n;
+            }
+        } else {
+            // ---- bf16-split K loop: one step = one (tap, 16-channel plane): 3 A reads per m-tile (one per term), 3 B loads
+            // per n-tile, SPLIT MFMAs per (m-tile, n-tile).  Both operand sets are prefetched one step ahead (ping-pong).
+            const f32x4* lds4 = (const f32x4*)lds;
+            // packed weights: [tap][Cin/16][term][Cout/32][64 lanes][8 bf16]
+            const float* wbase = a.wpk + ((size_t)(ch * a.kc) * 3 * cout32 + cg * NT) * 256 + lane * 4;
+            const size_t tap_stride = (size_t)(a.Cin >> 4) * 3 * cout32 * 256;
+            const size_t grp_stride = (size_t)3 * cout32 * 256;
+            const size_t term_stride = (size_t)cout32 * 256;
+            auto load_b = [&](f32x4 (*bf)[NT], int tw, int g) {
+                const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bf[s][j] = *(const f32x4*)(wp + s * term_stride + j * 256);
+            };
+            auto load_a = [&](f32x4 (*af)[MT], int toff4) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af[s][i] = lds4[lbase[i] + toff4 + s * 2];
+            };
+            auto mma = [&](const f32x4 (*af)[MT], const f32x4 (*bf)[NT]) {
+                // cross terms by decreasing significance index sum: a_sa * b_sb has weight 2^(-8 (sa + sb))
+#pragma unroll
+                for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+#pragma unroll
+                    for (int sa = 0; sa < 3; ++sa) {
+                        const int sb = sum - sa;
+                        if (sb < 0 || sb > 2) continue;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[sa][i]),
+                                                                                   __builtin_bit_cast(bf16x8, bf[sb][j]),
+                                                                                   acc[i][j], 0, 0, 0);
+                    }
+            };
+            f32x4 bq0[3][NT], bq1[3][NT], aq0[3][MT], aq1[3][MT];
+            load_b(bq0, a.tap_w[0], a.tap_g[0]);
+            __syncthreads();  // every wave is done reading the previous chunk's tile
+            stage_chunk(ch);
+            __syncthreads();
+            load_a(aq0, a.tap_off[0]);
+            int t = 0;
+            for (; t + 1 < a.ntaps; t += 2) {
+                // prefetches are unconditional (the last step re-fetches itself): branch-free body, counted waits
+                const int t2 = t + 2 < a.ntaps ? t + 2 : t + 1;
+                load_a(aq1, a.tap_off[t + 1]);
+                load_b(bq1, a.tap_w[t + 1], a.tap_g[t + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(aq0, bq0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_a(aq0, a.tap_off[t2]);
+                load_b(bq0, a.tap_w[t2], a.tap_g[t2]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(aq1, bq1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t < a.ntaps) mma(aq0, bq0);   // odd number of steps: the last one is already in the "0" registers
+        }
+    }
+
+    // ---- epilogue.  C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane
+    // holds ONE channel of 16 pixels.  Each wave transposes one m-tile at a time through a private LDS slab
+    // [32 pixels][NT*32 + 4] so that a lane then owns 4 consecutive channels of one pixel: 16-byte global stores,
+    // 16-byte residual / scale loads, and 4x fewer store instructions.  No block barrier after the first one:
+    // statistics are reduced per wave (shuffles) and written as one partial row per wave.
+    constexpr int LW = NT * 32 + 4;        // slab row pitch in floats (16-byte aligned, bank-staggered)
+    constexpr int Q = NT * 8;              // float4 quads per pixel row
+    constexpr int RPP = 64 / Q;            // pixel rows covered by one 64-lane pass
+    __syncthreads();                       // all waves are done with the input tile
+    float* slab = lds + wave * (32 * LW);
+    const int qc = lane % Q;               // this lane's channel quad
+    const int qr = lane / Q;               // and its row within a pass
+    f32x4 es = {1.f, 1.f, 1.f, 1.f}, eh = {0.f, 0.f, 0.f, 0.f};
+    if (flags & SPK_EPI_AFFINE) {
+        es = *(const f32x4*)(a.epi_scale + n0 + qc * 4);
+        eh = *(const f32x4*)(a.epi_shift + n0 + qc * 4);
+    }
+    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bsc = bmu, bsh = bmu;
+    if (flags & SPK_EPI_BNBWD) {
+        bmu = *(const f32x4*)(a.bn4 + n0 + qc * 4);
+        bis = *(const f32x4*)(a.bn4 + a.Cout + n0 + qc * 4);
+        bsc = *(const f32x4*)(a.bn4 + 2 * a.Cout + n0 + qc * 4);
+        bsh = *(const f32x4*)(a.bn4 + 3 * a.Cout + n0 + qc * 4);
+    }
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[row * LW + j * 32 + r] = acc[i][j][e];
+            }
+        // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
+#pragma unroll
+        for (int k = 0; k < 32 / RPP; ++k) {
+            const int row = k * RPP + qr;
+            const int ob = __shfl(obase[i], row, 64);
+            f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
+#ifdef ABL_NO_EPI
+            asm volatile("" ::"v"(v));
+            if (ob == -12345) {
+#else
+            if (ob >= 0) {
+#endif
+                float* dst = a.out + ob + qc * 4;
+                if (flags & SPK_EPI_AFFINE) v = v * es + eh;
+                if (flags & SPK_EPI_ADD) v += *(const f32x4*)(a.epi_add + ob + qc * 4);
+                if (flags & SPK_EPI_RELU) {
+                    v[0] = fmaxf(v[0], 0.f);
+                    v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f);
+                    v[3] = fmaxf(v[3], 0.f);
+                }
+                *(f32x4*)dst = v;
+                if (flags & SPK_EPI_BNBWD) {
+                    // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
+                    // its backward needs no separate reduction pass over this tensor
+                    const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
+                    f32x4 m;
+                    if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
+                    else m = rw * bsc + bsh;
+                    f32x4 dz;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                    ssum += dz;
+                    ssq += dz * ((rw - bmu) * bis);
+                } else {
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+    }
+    if (flags & SPK_EPI_STATS) {
+        // lanes with equal qc hold the same 4 channels: fold them (lane strides Q, 2Q, ... < 64)
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ssum[c] += __shfl_xor(ssum[c], off, 64);
+                ssq[c] += __shfl_xor(ssq[c], off, 64);
+            }
+        }
+        if (lane < Q) {
+            float* dst = a.stats + ((size_t)(ptile * 4 + wave) * a.Cout + n0 + lane * 4) * 2;
+            *(f32x4*)dst = (f32x4){ssum[0], ssq[0], ssum[1], ssq[1]};
+            *(f32x4*)(dst + 4) = (f32x4){ssum[2], ssq[2], ssum[3], ssq[3]};
+        }
+    }
+}
+

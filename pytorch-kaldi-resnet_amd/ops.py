@@ -1,6 +1,7 @@
 """Thin Python wrappers over the libspkhip exports: shape checks, output allocation (torch caching
 allocator owns every device buffer), tile selection, tap tables.  No arithmetic happens here."""
 import ctypes
+import os
 
 import torch
 
@@ -38,17 +39,32 @@ def conv_out_hw(h, w, ksize, stride):
     return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
 
 
+# Matrix-core operand mode of the 3x3 convolutions (forward and data gradient): 0 = fp32 operands on
+# v_mfma_f32_32x32x2_f32; 6 / 9 = each fp32 operand split exactly into three bf16 terms, 6 (or all 9) cross terms on
+# v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/conv_kernel.h).  Packed weights carry the mode: change it only
+# together with a repack (Engine.set_mfma_mode).
+MFMA_MODES = {"f32": 0, "bf16x6": 6, "bf16x9": 9}
+SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "f32")]
+
+
+def split_for(ksize):
+    return SPLIT if ksize == 3 else 0
+
+
 def pack_conv_weight(w, transpose=False, out=None):
-    """OIHW nn.Conv2d weight -> MFMA fragment order (see csrc/conv_mfma.hip)."""
+    """OIHW nn.Conv2d weight -> MFMA fragment order (see csrc/conv_mfma.hip, csrc/conv_split.hip)."""
     Cout, Cin, KH, KW = w.shape
-    if out is None:
-        out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-    call("spk_pack_conv_weight", ptr(w), ptr(out), Cout, Cin, KH, KW, 1 if transpose else 0, stream())
+    split = split_for(KH)
+    n = w.numel() * 3 // 2 if split else w.numel()      # three bf16 terms = 6 bytes per weight
+    if out is None or out.numel() != n:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    call("spk_pack_conv_weight_split" if split else "spk_pack_conv_weight", ptr(w), ptr(out), Cout, Cin, KH, KW,
+         1 if transpose else 0, stream(), label="spk_pack_conv_weight")
     return out
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
-                 bn_bwd=None, in_bnbwd=None, side=None):
+                 bn_bwd=None, in_bnbwd=None, side=None, split=0):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -59,7 +75,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         ips, IS = IS, 1          # strided 1x1: address the input through a strided view, stage only the pixels used
     key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
     if tiling.AUTOTUNE and key not in tiling.FORCE_CONV and PROFILE is None and not torch.cuda.is_current_stream_capturing():
-        _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu)
+        _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split)
     TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0)
     # single-tap (1x1) convolutions stage several 32-channel planes per barrier: their K loop per plane is only 4 MFMA groups
     kc = 1
@@ -101,8 +117,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(side[0]) if side else None, ptr(side[1]) if side else None,
          ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
-         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, stream(),
-         label="conv_mfma_kernel<%d,%d,%s>" % (MT, NT, "true" if in_bnbwd is not None else "false"),
+         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, stream(),
+         label="conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
 
@@ -118,7 +134,7 @@ def _time_launch(fn, reps=2):
     return e0.elapsed_time(e1) / reps
 
 
-def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu):
+def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split=0):
     """Time candidate tiles on the real operands (scratch output) and pin the fastest for this launch shape."""
     scratch = torch.empty_like(out)
     add = epi_add if (epi_add is None or epi_add.data_ptr() != out.data_ptr()) else scratch
@@ -127,7 +143,7 @@ def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_af
         tiling.FORCE_CONV[key] = cand
         try:
             ms = _time_launch(lambda: _conv_launch(x, wpk, scratch, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine,
-                                                   epi_affine, add, relu, True))
+                                                   epi_affine, add, relu, True, split=split))
         except RuntimeError:
             continue
         if best is None or ms < best[0]:
@@ -166,7 +182,8 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
         taps = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
     else:
         taps = [(0, 0, 0)]
-    st = _conv_launch(x, wpk, out, Cout, taps, stride, 1, 0, 0, OH, OW, in_affine, epi_affine, epi_add, relu, stats)
+    st = _conv_launch(x, wpk, out, Cout, taps, stride, 1, 0, 0, OH, OW, in_affine, epi_affine, epi_add, relu, stats,
+                      split=split_for(ksize))
     return out, st
 
 
@@ -193,7 +210,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
         else:
             taps = [(0, 0, 0)]
         st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd, in_bnbwd,
-                          side)
+                          side, split=split_for(ksize))
         return (out, st) if bn_bwd is not None else out
     assert stride == 2 and bn_bwd is None and in_bnbwd is None
     if ksize == 1:
@@ -219,7 +236,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
                     if (cx + 1 - kw) % 2:
                         continue
                     taps.append(((cy + 1 - kh) // 2, (cx + 1 - kw) // 2, kh * 3 + kw))
-            _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False)
+            _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False, split=split_for(3))
     return out
 
 

@@ -55,9 +55,21 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["f32", "bf16x6", "bf16x9"])
+def mfma_mode(request, ops):
+    """operand mode of the 3x3 convolutions: native fp32 MFMA, or fp32 operands split into three bf16 terms with the 6 /
+    9 cross terms on the bf16 MFMA (fp32 accumulate).  Every mode must meet the SAME tolerances below."""
+    old = ops.SPLIT
+    ops.SPLIT = ops.MFMA_MODES[request.param]
+    yield request.param
+    ops.SPLIT = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(ops, case):
+def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     B, Cin, Cout, H, Wd, k, s = case
+    if k == 1 and mfma_mode != "f32":
+        pytest.skip("1x1 convolutions always run on the fp32 MFMA")
     pad = 1 if k == 3 else 0
     x = rnd(1, B, Cin, H, Wd)
     w = rnd(2, Cout, Cin, k, k, scale=0.2)
