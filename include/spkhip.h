@@ -83,7 +83,8 @@ size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
 int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate, void* stream);
 int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                    const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,
-                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, void* stream);
+                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, int split /* 0, or 6 / 9 = bf16-split operands
+                   (3x3 only), see spk_conv_mfma */, void* stream);
 
 /* Stem Conv2d(1,32,3,1,1,bias=False) (scripts/model.py:210,249): x [B][F][T] -> out [B][F][T][32];
  * stats (EPI_STATS): [spk_stem_fwd_blocks()][32][2]. */

@@ -5,8 +5,6 @@
 #define STAGE_U 4   // staging loads in flight per thread
 #endif
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 // SPLIT == 0: operands stay fp32 (v_mfma_f32_32x32x2_f32).  SPLIT == 6 / 9: every fp32 operand is split into three bf16
 // terms (x = x1 + x2 + x3 exactly: 3 x 8 significand bits) while it is staged (activations) or packed (weights), and the
 // product is formed from the 6 (or all 9) cross terms of weight >= 2^-16 (2^-24) on v_mfma_f32_32x32x16_bf16 with fp32
@@ -21,23 +19,6 @@ struct ConvCfg {
     // are odd multiples of 16 B, so the 8 lanes of a ds_read_b128 phase (consecutive pixels) hit distinct bank groups.
     static constexpr int LP4 = SPLIT ? 7 : 9;
 };
-
-static __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi, float& rlo, float& rhi) {
-    const __bf16 a = (__bf16)lo, b = (__bf16)hi;   // round to nearest even
-    rlo = lo - (float)a;                           // exact in fp32
-    rhi = hi - (float)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-// w -> three bf16 quads (8 bytes each): w = t0 + t1 + t2
-static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uint2& t2) {
-    float r0, r1, r2, r3, q0, q1, q2, q3;
-    t0.x = pack_bf16x2(w[0], w[1], r0, r1);
-    t0.y = pack_bf16x2(w[2], w[3], r2, r3);
-    t1.x = pack_bf16x2(r0, r1, q0, q1);
-    t1.y = pack_bf16x2(r2, r3, q2, q3);
-    t2.x = pack_bf16x2(q0, q1, r0, r1);
-    t2.y = pack_bf16x2(q2, q3, r2, r3);
-}
 
 struct ConvArgs {
     const float* in;

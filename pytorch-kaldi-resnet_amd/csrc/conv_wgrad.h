@@ -1,0 +1,25 @@
+// Shared by conv_wgrad.hip (fp32 operands) and conv_wgrad_split.hip (bf16-split operands).
+#pragma once
+#include "spk_common.h"
+
+#ifndef WGRAD_NX
+#define WGRAD_NX 5   // prefetch registers (float4) per thread for the X halo tile: halo_pix <= 32*NX
+#endif
+#ifndef WGRAD_ND
+#define WGRAD_ND 4   // and for the dY tile: npix <= (256/(8*WN))*ND
+#endif
+
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* partial;
+    const float* in_scale;
+    const float* in_shift;
+    int B, IH, IW, Cin, OH, OW, Cout;
+    int S, KW, pad;
+    int TH, TW, tiles_y, tiles_x, nregions, nsplit;
+    int halo_h, halo_w;
+    unsigned halo_w_magic, tw_magic;   // ceil(2^32 / d) for exact small-range division
+    int flags;
+};
+

@@ -11,28 +11,10 @@
 // order (deterministic) and writes OIHW.
 // (ABL_NO_* macros select diagnostic ablation builds - wrong results by construction - used to price each phase of the
 //  kernel: SPK_CXXFLAGS="-DABL_NO_STAGE" python build.py, then SPK_LIB=<variant.so> tools/conv_bench.py.)
-#include "spk_common.h"
+#include "conv_wgrad.h"
 
-#ifndef WGRAD_NX
-#define WGRAD_NX 5   // prefetch registers (float4) per thread for the X halo tile: halo_pix <= 32*NX
-#endif
-#ifndef WGRAD_ND
-#define WGRAD_ND 4   // and for the dY tile: npix <= (256/(8*WN))*ND
-#endif
-
-struct WgradArgs {
-    const float* x;
-    const float* dy;
-    float* partial;
-    const float* in_scale;
-    const float* in_shift;
-    int B, IH, IW, Cin, OH, OW, Cout;
-    int S, KW, pad;
-    int TH, TW, tiles_y, tiles_x, nregions, nsplit;
-    int halo_h, halo_w;
-    unsigned halo_w_magic, tw_magic;   // ceil(2^32 / d) for exact small-range division
-    int flags;
-};
+// bf16-split instantiations live in conv_wgrad_split.hip
+int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st);
 
 template <int NTAPS, int WK, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -287,7 +269,7 @@ extern "C" int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int 
 extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                               const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout,
                               int ksize, int stride, int TH, int TW, int WN, int nsplit, int flags, int accumulate,
-                              void* stream) {
+                              int split, void* stream) {
     SPK_REQUIRE(x && dy && dw && partial, "spk_conv_wgrad: null pointer");
     SPK_REQUIRE(ksize == 1 || ksize == 3, "spk_conv_wgrad: ksize=%d unsupported", ksize);
     SPK_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "spk_conv_wgrad: channels (%d,%d) must be multiples of 32", Cin, Cout);
@@ -310,16 +292,18 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
     a.tw_magic = (unsigned)((0x100000000ULL + (unsigned long long)TW - 1) / (unsigned long long)TW);
     a.flags = flags;
+    SPK_REQUIRE(split == 0 || ((split == 6 || split == 9) && ksize == 3), "spk_conv_wgrad: split=%d (0, or 6 / 9 for 3x3)", split);
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",
+                a.halo_h, a.halo_w, 32 * WGRAD_NX);
+    SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
+                TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
+    if (split) return spk_launch_wgrad_split(a, WN, split, (hipStream_t)stream);
     const int ntaps = ksize * ksize;
     const int WK = 4 / WN;
     size_t lds_bytes = ((size_t)a.halo_h * a.halo_w * 32 + (size_t)TH * TW * WN * 32) * sizeof(float);
     const size_t red_bytes = (WK > 1) ? (size_t)WN * ntaps * 16 * 64 * sizeof(float) : 0;
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad: tile %dx%d needs %zu B of LDS", TH, TW, lds_bytes);
-    SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",
-                a.halo_h, a.halo_w, 32 * WGRAD_NX);
-    SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
-                TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
     hipStream_t st = (hipStream_t)stream;
     int rc = -1;
     if (ntaps == 9) {

@@ -1,0 +1,250 @@
+// Weight gradient of the 3x3 convolutions with bf16-split operands (see conv_wgrad.hip for the fp32-operand kernel and
+// conv_kernel.h for the splitting idea): fp32 X and dY go in, fp32 dW comes out; each operand value is staged into LDS as
+// three bf16 terms whose sum is the fp32 value and the 6 most significant (or all 9) cross terms are multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// GEMM view per tap: D[ci][co] += sum_k X[pixel k shifted by the tap][ci] * dY[pixel k][co], k = 16 output pixels per
+// MFMA.  Both operands are K-strided in memory ([pixel][channel]), so the LDS images stay [pixel][term][32 channels]
+// (one ds_write_b64 per term while publishing) and the fragments are gathered with the gfx950 transposing read
+// ds_read_b64_tr_b16: a 16-lane group reads 4 pixel rows x 16 channels and every lane receives ITS channel of the four
+// pixels - two such reads are the 8 consecutive k of a lane's A (or B) operand.  Row pitches of 192 B (X) and
+// WN*192 (+64) B (dY) put the four rows of a block 192 B (mod 256) apart: conflict-free.
+#include "conv_wgrad.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int WK, int WN, int SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    constexpr int NTAPS = 9;
+    constexpr int PX = 192;                               // X bytes per staged pixel: [3 terms][32 ch bf16]
+    constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);      // dY bytes per pixel: [WN][3 terms][32 ch bf16] (+ pad)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int wk = wave / WN, wn = wave % WN;
+    const int ci0 = blockIdx.y * 32;
+    const int co0 = blockIdx.z * (32 * WN);
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int npix = a.TH * a.TW;
+    const int nsteps_all = (npix + 15) >> 4;              // k-steps of 16 pixels; the padding rows of dY are zero
+    const int npix_pad = nsteps_all << 4;
+    unsigned char* xs = ldsb;
+    unsigned char* dys = ldsb + halo_pix * PX;
+    const int flags = a.flags;
+
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int quad = tid & 7;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (flags & SPK_IN_AFFINE_RELU) {
+        sc = *(const f32x4*)(a.in_scale + ci0 + quad * 4);
+        sh = *(const f32x4*)(a.in_shift + ci0 + quad * 4);
+    }
+
+    // region pipeline as in conv_wgrad.hip: next region's global loads fly during this region's MFMAs
+    constexpr int NX = WGRAD_NX, ND = WGRAD_ND;
+    constexpr int QPP = WN * 8;
+    constexpr int PSTEP = 256 / QPP;
+    const int cq = tid % QPP;
+    f32x4 px[NX], pd[ND];
+    unsigned inx = 0, ind = 0;
+
+    auto prefetch = [&](int region) {
+        int pt = region;
+        const int tx = pt % a.tiles_x;
+        pt /= a.tiles_x;
+        const int ty = pt % a.tiles_y;
+        const int b = pt / a.tiles_y;
+        const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+        const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
+        inx = 0;
+        ind = 0;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            int p = (tid >> 3) + 32 * u;
+            p = p < halo_pix ? p : halo_pix - 1;
+            const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+            const int hx = p - hy * a.halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) inx |= 1u << u;
+            const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+            px[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int p0 = tid / QPP + PSTEP * u;
+            const int p = p0 < npix ? p0 : npix - 1;
+            const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+            const int lx = p - ly * a.TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            if (p0 < npix && oy < a.OH && ox < a.OW) ind |= 1u << u;
+            const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
+            pd[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+        }
+    };
+    auto publish = [&]() {      // registers -> three bf16 terms in LDS (zero outside the image / tile; fused BN+ReLU on X)
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int p = (tid >> 3) + 32 * u;
+            f32x4 w = px[u];
+            if (flags & SPK_IN_AFFINE_RELU) {
+                w = w * sc + sh;
+                w[0] = fmaxf(w[0], 0.f);
+                w[1] = fmaxf(w[1], 0.f);
+                w[2] = fmaxf(w[2], 0.f);
+                w[3] = fmaxf(w[3], 0.f);
+            }
+            if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < halo_pix) {
+                uint2 t0, t1, t2;
+                split3(w, t0, t1, t2);
+                uint2* dst = (uint2*)(xs + p * PX) + quad;
+                dst[0] = t0;
+                dst[8] = t1;
+                dst[16] = t2;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int p = tid / QPP + PSTEP * u;
+            const f32x4 w = ((ind >> u) & 1) ? pd[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < npix_pad) {
+                uint2 t0, t1, t2;
+                split3(w, t0, t1, t2);
+                uint2* dst = (uint2*)(dys + p * PD + (cq >> 3) * 192) + (cq & 7);
+                dst[0] = t0;
+                dst[8] = t1;
+                dst[16] = t2;
+            }
+        }
+    };
+
+    // per-lane roles in the transposing reads: 16-lane group g16 = (channel half, k half); within it lane 4q+p addresses
+    // pixel row q, channels 4p..4p+3 of the group's 16 channels
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int col_off = (g16 & 1) * 32 + p4 * 8;
+
+    auto mma = [&](f32x16& c, const s16x8* af, const s16x8* bf) {
+#pragma unroll
+        for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+#pragma unroll
+            for (int sa = 0; sa < 3; ++sa) {
+                const int sb = sum - sa;
+                if (sb < 0 || sb > 2) continue;
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[sa]), __builtin_bit_cast(bf16x8, bf[sb]), c,
+                                                            0, 0, 0);
+            }
+    };
+
+    int region = blockIdx.x;
+    if (region < a.nregions) prefetch(region);
+    for (; region < a.nregions; region += a.nsplit) {
+        __syncthreads();   // previous region fully consumed
+        publish();
+        __syncthreads();
+        if (region + a.nsplit < a.nregions) prefetch(region + a.nsplit);
+
+        for (int j = wk; j < nsteps_all; j += WK) {
+            int xa[2], da[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int pix = j * 16 + 8 * h + 4 * blk + q;
+                const int pc = pix < npix ? pix : npix - 1;      // padding rows: any valid X address (their dY is zero)
+                const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
+                const int lx = pc - ly * a.TW;
+                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + col_off;
+                da[blk] = pix * PD + wn * 192 + col_off;
+            }
+            s16x8 bf[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bf[s] = tr_read8(dys + da[0] + s * 64, dys + da[1] + s * 64);
+            s16x8 a0[3], a1[3];
+            auto load_a = [&](s16x8* af, int t) {
+                const int toff = ((t / 3) * a.halo_w + (t % 3)) * PX;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) af[s] = tr_read8(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+            };
+            load_a(a0, 0);
+#pragma unroll
+            for (int t = 0; t < NTAPS; t += 2) {
+                if (t + 1 < NTAPS) load_a(a1, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(acc[t], a0, bf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < NTAPS) load_a(a0, t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) mma(acc[t + 1], a1, bf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // fold the WK pixel-splits into wk == 0 through LDS (fixed order -> deterministic), then one slab per block
+    const int r = lane & 31;
+    if (WK > 1) {
+        float* red = (float*)ldsb;  // [WN][NTAPS][16][64]
+#pragma unroll 1
+        for (int src = 1; src < WK; ++src) {
+            __syncthreads();
+            if (wk == src) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((wn * NTAPS + t) * 16 + e) * 64 + lane] = acc[t][e];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] += red[((wn * NTAPS + t) * 16 + e) * 64 + lane];
+            }
+        }
+    }
+    if (wk == 0) {
+        float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = acc[t][e];
+            }
+    }
+}
+
+template <int WK, int WN>
+static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
+    const int npix_pad = ((a.TH * a.TW + 15) >> 4) << 4;
+    constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);
+    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 192 + (size_t)npix_pad * PD;
+    const size_t red_bytes = (WK > 1) ? (size_t)WN * 9 * 16 * 64 * sizeof(float) : 0;
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(split): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
+    dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
+    if (split == 6)
+        hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6>), grid, dim3(256), lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9>), grid, dim3(256), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_wgrad(split)");
+    return 0;
+}
+
+int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st) {
+    if (WN == 1) return launch_one<4, 1>(a, split, st);
+    if (WN == 2) return launch_one<2, 2>(a, split, st);
+    return launch_one<1, 4>(a, split, st);
+}

@@ -36,3 +36,25 @@ enum {
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- bf16 operand splitting (device): an fp32 value is the exact sum of three bf16 terms (3 x 8 significand bits)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef __HIPCC__
+static __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi, float& rlo, float& rhi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;   // round to nearest even
+    rlo = lo - (float)a;                           // exact in fp32
+    rhi = hi - (float)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// w -> three bf16 quads (8 bytes each): w = t0 + t1 + t2
+static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uint2& t2) {
+    float r0, r1, r2, r3, q0, q1, q2, q3;
+    t0.x = pack_bf16x2(w[0], w[1], r0, r1);
+    t0.y = pack_bf16x2(w[2], w[3], r2, r3);
+    t1.x = pack_bf16x2(r0, r1, q0, q1);
+    t1.y = pack_bf16x2(r2, r3, q2, q3);
+    t2.x = pack_bf16x2(q0, q1, r0, r1);
+    t2.y = pack_bf16x2(q2, q3, r2, r3);
+}
+#endif
+

@@ -74,9 +74,9 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     if len(taps) == 1 and IS > 1 and dys[0] == 0 and dxs[0] == 0:
         ips, IS = IS, 1          # strided 1x1: address the input through a strided view, stage only the pixels used
     key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
-    if tiling.AUTOTUNE and key not in tiling.FORCE_CONV and PROFILE is None and not torch.cuda.is_current_stream_capturing():
+    if tiling.AUTOTUNE and key not in (tiling.FORCE_CONV_SPLIT if split else tiling.FORCE_CONV) and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split)
-    TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0)
+    TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0, split=split)
     # single-tap (1x1) convolutions stage several 32-channel planes per barrier: their K loop per plane is only 4 MFMA groups
     kc = 1
     if len(taps) == 1:
@@ -139,8 +139,9 @@ def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_af
     scratch = torch.empty_like(out)
     add = epi_add if (epi_add is None or epi_add.data_ptr() != out.data_ptr()) else scratch
     best = None
-    for cand in tiling.conv_candidates(*key):
-        tiling.FORCE_CONV[key] = cand
+    table = tiling.FORCE_CONV_SPLIT if split else tiling.FORCE_CONV
+    for cand in tiling.conv_candidates(*key, split=split):
+        table[key] = cand
         try:
             ms = _time_launch(lambda: _conv_launch(x, wpk, scratch, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine,
                                                    epi_affine, add, relu, True, split=split))
@@ -149,9 +150,9 @@ def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_af
         if best is None or ms < best[0]:
             best = (ms, cand)
     if best is None:
-        del tiling.FORCE_CONV[key]
+        del table[key]
     else:
-        tiling.FORCE_CONV[key] = best[1]
+        table[key] = best[1]
 
 
 def _autotune_wgrad(key, x, dy, ksize, stride, in_affine):
@@ -269,8 +270,10 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     flags = IN_AFFINE_RELU if in_affine is not None else 0
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
-         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, stream(),
-         label="conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
+         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split_for(ksize),
+         stream(),
+         label=("conv_wgrad_split_kernel<%d,%d,%d>" % (4 // WN, WN, split_for(ksize))) if split_for(ksize)
+         else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw

@@ -21,17 +21,20 @@ WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
 
 # Measured overrides (tools/conv_bench.py --sweep on MI355X): key -> (TH, TW, MT, NT) / (TH, TW, WN)
 FORCE_CONV = {}
+FORCE_CONV_SPLIT = {}     # the same launch shapes in the bf16-split operand mode (112 B of LDS per pixel, faster MFMA phase)
 FORCE_WGRAD = {}
 
 
 def _load_table():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+    path = os.environ.get("SPK_TILE_TABLE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json"))
     if os.path.exists(path):
         t = json.load(open(path))
         for k, v in t.get("conv", {}).items():
             FORCE_CONV[tuple(int(x) for x in k.split(","))] = tuple(v)
+        for k, v in t.get("conv_split", {}).items():
+            FORCE_CONV_SPLIT[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("wgrad", {}).items():
             FORCE_WGRAD[tuple(int(x) for x in k.split(","))] = tuple(v)
 
@@ -41,19 +44,22 @@ def _load_table():
 AUTOTUNE = _os.environ.get("SPK_AUTOTUNE", "0") == "1"
 
 
-def conv_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_config=3):
+def conv_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_config=3, split=0):
     """Candidate (TH, TW, MT, NT) tiles: for every register configuration the best-utilised few shapes."""
     cands = []
+    pix_bytes = 112 if split else LDS_PIX_BYTES
     for MT in (1, 2, 3, 4):
         cap = 128 * MT
         for NT in (1, 2, 4):
             if Cout % (32 * NT) or MT * NT > 8 or (MT * NT == 8 and MT == 4):
                 continue
+            if split and (MT, NT) not in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2), (1, 4)):
+                continue
             best = []
             for TH in range(1, min(OH, cap) + 1):
                 for TW in range(1, min(OW, cap // TH) + 1):
                     halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
-                    if halo * LDS_PIX_BYTES > LDS_HARD:
+                    if halo * pix_bytes > LDS_HARD:
                         continue
                     ty, tx = -(-OH // TH), -(-OW // TW)
                     best.append((-(OH * OW) / (ty * tx * cap), halo / (TH * TW), TH, TW))
@@ -78,10 +84,16 @@ def wgrad_candidates(OH, OW, Cin, Cout, ksize, stride, per_config=4):
     return out
 
 
-def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0):
+def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     """mode 1 = data gradient with the BatchNorm backward fused into its input staging (heavier staging: it may prefer
-    wider channel tiles); table keys carry the mode as an 8th element and fall back to the plain entry."""
+    wider channel tiles); table keys carry the mode as an 8th element and fall back to the plain entry.  split != 0
+    (bf16-split operands) consults its own table first."""
     key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
+    if split:
+        if mode and key + (mode,) in FORCE_CONV_SPLIT:
+            return FORCE_CONV_SPLIT[key + (mode,)]
+        if key in FORCE_CONV_SPLIT:
+            return FORCE_CONV_SPLIT[key]
     if mode and key + (mode,) in FORCE_CONV:
         return FORCE_CONV[key + (mode,)]
     if key in FORCE_CONV:

@@ -137,9 +137,11 @@ def test_backward_parity(P, gold_dir, name):
             e = float((hip[n] - g64[n]).norm() / g64[n].norm())
             assert e < 5e-4, (n, e)
     # golden norms recorded from the reference itself
+    # (2 %, or 1.5x the fp32 oracle's own whole-gradient error against fp64 where that is larger: ResNet-101 at batch 2)
+    tol = max(2e-2, 1.5 * e_oracle)
     for i, n in enumerate(names):
         ref = float(g["grad_norm"][i])
-        assert abs(float(hip[n].norm()) - ref) <= 2e-2 * ref + 1e-5, n
+        assert abs(float(hip[n].norm()) - ref) <= tol * ref + 1e-5, n
 
 
 def test_fused_step_equals_autograd_path(P, gold_dir):

@@ -19,6 +19,7 @@ from pytorch_kaldi_resnet_amd import ops, tiling  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--sweep-bnbwd", action="store_true", help="sweep tiles of the stride-1 data gradients in fused BatchNorm-backward mode and merge them into the table")
+ap.add_argument("--no-wgrad", action="store_true", help="with --sweep: leave the weight-gradient table alone")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--feat", type=int, default=80)
@@ -60,13 +61,17 @@ for i, (c, h, w) in enumerate(dims):
 
 
 def conv_candidates(OH, OW, IS, ks, Cout):
-    return sorted(set(tiling.conv_candidates(OH, OW, IS, ks, ks, ks * ks, Cout, per_config=6)))
+    return sorted(set(tiling.conv_candidates(OH, OW, IS, ks, ks, ks * ks, Cout, per_config=6, split=ops.split_for(ks))))
 
 
-table = {"conv": {}, "wgrad": {}}
+# the operand mode comes from SPK_MFMA (ops.SPLIT): split-mode sweeps fill the "conv_split" section of the table
+SECTION = "conv_split" if ops.SPLIT else "conv"
+FORCE = tiling.FORCE_CONV_SPLIT if ops.SPLIT else tiling.FORCE_CONV
+table = json.load(open(args.out)) if os.path.exists(args.out) else {}
+for sec in ("conv", "conv_split", "wgrad"):
+    table.setdefault(sec, {})
 rows = []
 if args.sweep_bnbwd:
-    table = json.load(open(args.out))
     for name, Cin, Cout, H, W, k, s in shapes:
         if k != 3 or s != 1:
             continue
@@ -81,7 +86,7 @@ if args.sweep_bnbwd:
         key = (H, W, 1, 3, 3, 9, C)
         res = []
         for cand in conv_candidates(H, W, 1, 3, C):
-            tiling.FORCE_CONV[key + (1,)] = cand
+            FORCE[key + (1,)] = cand
             try:
                 ms = timeit(lambda: ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, W), out=dx, bn_bwd=(raw_p, None, bn4),
                                                    in_bnbwd=(raw, act, bn4, coef), side=(draw, dz)), args.reps)
@@ -89,9 +94,9 @@ if args.sweep_bnbwd:
                 continue
             res.append((ms, cand))
         res.sort()
-        tiling.FORCE_CONV[key + (1,)] = res[0][1]
-        table["conv"][",".join(map(str, key + (1,)))] = list(res[0][1])
-        cur = [m for m, c in res if tuple(c) == tuple(tiling.FORCE_CONV.get(key, ()))]
+        FORCE[key + (1,)] = res[0][1]
+        table[SECTION][",".join(map(str, key + (1,)))] = list(res[0][1])
+        cur = [m for m, c in res if tuple(c) == tuple(FORCE.get(key, tiling.FORCE_CONV.get(key, ())))]
         print("%-12s bnbwd-dgrad best %s %.3f ms %.1f TF (plain-table tile: %s) | top: %s" % (
             name, res[0][1], res[0][0], flops / res[0][0] / 1e9, "%.3f ms" % cur[0] if cur else "n/a",
             " ".join("%s:%.3f" % (c, m) for m, c in res[:6])), flush=True)
@@ -110,24 +115,25 @@ for name, Cin, Cout, H, W, k, s in shapes:
     dx = torch.empty(B, H, W, Cin, device=dev)
     flops = 2.0 * B * OH * OW * Cout * Cin * k * k
     key = (OH, OW, s if k == 3 else 1, k, k, k * k, Cout)      # strided 1x1 launches run as IS = 1 over a strided view
-    if args.sweep:
+    if args.sweep and (k == 3 or not ops.SPLIT):
         res = []
+        tab = FORCE if k == 3 else tiling.FORCE_CONV
         for cand in conv_candidates(OH, OW, s if k == 3 else 1, k, Cout):
-            tiling.FORCE_CONV[key] = cand
+            tab[key] = cand
             try:
                 ms = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
             except RuntimeError as e:
                 continue
             res.append((ms, cand))
         res.sort()
-        tiling.FORCE_CONV[key] = res[0][1]
-        table["conv"][",".join(map(str, key))] = list(res[0][1])
+        tab[key] = res[0][1]
+        table[SECTION if k == 3 else "conv"][",".join(map(str, key))] = list(res[0][1])
         print("%-12s fwd best %s %.3f ms %.1f TF | top: %s" % (name, res[0][1], res[0][0], flops / res[0][0] / 1e9,
               " ".join("%s:%.3f" % (c, m) for m, c in res[:5])), flush=True)
         if s == 1 and k == 3:
             # the stride-1 data gradient is the same launch shape with Cin/Cout swapped (equal here)
             pass
-    if args.sweep:
+    if args.sweep and not args.no_wgrad:
         wkey = (OH, OW, Cin, Cout, k, s)
         res = []
         OWe = OW + (OW & 1)
@@ -158,7 +164,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
     rows.append((name, flops, t_fwd, t_dg, t_wg))
     print("%-12s %6.1f GF  fwd %.3f ms %5.1f TF  dgrad %.3f ms %5.1f TF  wgrad %.3f ms %5.1f TF   tiles %s / %s" % (
         name, flops / 1e9, t_fwd, flops / t_fwd / 1e9, t_dg, flops / t_dg / 1e9, t_wg, flops / t_wg / 1e9,
-        tiling.conv_tile(*key), tiling.wgrad_tile(OH, OW, Cin, Cout, k, s)), flush=True)
+        tiling.conv_tile(*key, split=ops.split_for(k)), tiling.wgrad_tile(OH, OW, Cin, Cout, k, s)), flush=True)
 if args.sweep:
     json.dump(table, open(args.out, "w"), indent=1)
     print("wrote", args.out)
