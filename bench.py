@@ -27,6 +27,21 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, FEAT, FRAMES, SPK = 256, 80, 300, 1211
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: dense bf16 matrix (no sparsity)
+
+
+def mfma_peak(kernel_label):
+    """Peak rate of ALGORITHMIC fp32 FLOPs for a kernel: the fp32 matrix peak for fp32-operand kernels; for the bf16-split
+    kernels every fp32 multiply-add costs 6 (or 9) bf16 ones, so the dense bf16 peak divided by that."""
+    inner = kernel_label[kernel_label.find("<") + 1:kernel_label.rfind(">")].split(",") if "<" in kernel_label else []
+    terms = 0
+    if kernel_label.startswith("conv_mfma_kernel") and len(inner) == 4:
+        terms = int(inner[3])
+    elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 3:
+        terms = int(inner[2])
+    if terms:
+        return PEAK_BF16_MFMA_TFLOPS / terms, "bf16 dense peak / %d cross products per fp32 multiply-add" % terms
+    return PEAK_F32_MFMA_TFLOPS, "fp32 dense matrix peak"
 
 
 def parse():
@@ -45,6 +60,9 @@ def parse():
     ap.add_argument("--frames-range", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="one chunk length per step, uniform in [LO, HI] (seeded) like the reference's variable-length "
                          "batches (scripts/datasets.py:178-193); implies eager launches")
+    ap.add_argument("--mfma", choices=["bf16x6", "bf16x9", "f32"], default=None,
+                    help="operand mode of the 3x3 convolutions (default: the package default, bf16x6 = fp32 operands as three "
+                         "exact bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate; f32 = native fp32 MFMA)")
     ap.add_argument("--autotune", action="store_true", help="time candidate tiles on first use of a launch shape (SPK_AUTOTUNE=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -141,6 +159,9 @@ def main():
 
     torch.manual_seed(0)
     import contextlib
+    if args.mfma:
+        ops.SPLIT = ops.MFMA_MODES[args.mfma]
+    mfma_mode = {v: k for k, v in ops.MFMA_MODES.items()}[ops.SPLIT]
     if args.autotune:
         from pytorch_kaldi_resnet_amd import tiling
         tiling.AUTOTUNE = True
@@ -270,17 +291,43 @@ def main():
             ent = json.load(open(pmc))["kernels"].get(name.replace(",", ", "))
             if ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak, peak_note = mfma_peak(name)
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "peak_note": peak_note,
+                    "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                     "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
                     "gflop_per_launch": round(fsum / n / 1e9, 3),
                     "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
                                         "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
                                         "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
+    headline = args.arch == "resnet34" and nspk == SPK and var_x is None
+    native = None
+    if rank == 0 and world == 1 and args.mode == "train" and headline and graphed is not None and ops.SPLIT != 0 \
+            and not args.no_roofline:
+        # the same step on the native fp32 matrix instruction, timed the same way, for comparison (N = 1 only)
+        from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
+        keep = ops.SPLIT
+        ops.SPLIT = 0
+        eng.dirty = True
+        g32 = GraphedTrainStep(eng, args.batch, args.frames)
+        for _ in range(2):
+            g32(x, y)
+            opt.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g32(x, y)
+            opt.step()
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - t1
+        native = {"mfma": "f32", "value": round(args.batch * args.steps / d32, 2), "unit": "utt/s",
+                  "ms_per_step": round(d32 / args.steps * 1e3, 3)}
+        ops.SPLIT = keep
+        eng.dirty = True
+        log("fp32-operand comparison run done: %.1f utt/s" % native["value"])
     cpu = None
     parity = None
-    headline = args.arch == "resnet34" and nspk == SPK and var_x is None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train" and headline:
         log("roofline pass done; timing the CPU oracle (bounded sample)")
         cpu = cpu_baseline(args)
@@ -296,16 +343,19 @@ def main():
             if args.mode == "train" else "utterances/sec, eval-mode embedding extraction (predict), %s" % arch_name,
             "value": round(gb * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if ops.SPLIT == 0 else "f32 (operands as 3 exact bf16 terms, %d cross products, f32 accumulate)" % ops.SPLIT,
+            "data": "synthetic",
             "config": {"workload": "%s: %s + AAM-softmax (m 0.2, s 30), %d speakers, "
                                    "%s x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
                                    % ("BASELINE configs[1]" if headline else "non-headline case", arch_name, nspk,
                                       frames_desc, FEAT, args.batch),
                        "global_batch": gb, "frames": args.frames if var_x is None else list(args.frames_range),
                        "feat_dim": FEAT, "speakers": nspk,
-                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed is not None else "eager"},
+                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed is not None else "eager",
+                       "mfma": mfma_mode},
             "final_loss": round(lossv, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native,
             "embedding_cosine_delta_vs_oracle": parity,
         }
         print(json.dumps(out))

@@ -30,6 +30,17 @@ from oracle import weights as W  # noqa: E402
 CASES = ["c1_r34_aam", "r34_aam_t203", "r34_aam_t300", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"]
 
 
+@pytest.fixture(autouse=True, params=["bf16x6", "f32"])
+def mfma_mode(request):
+    """Every model-level parity test runs in the default operand mode (fp32 operands as three bf16 terms, 6 cross products
+    on the bf16 matrix instruction, fp32 accumulate) and on the native fp32 matrix instruction - same tolerances."""
+    from pytorch_kaldi_resnet_amd import ops
+    old = ops.SPLIT
+    ops.SPLIT = ops.MFMA_MODES[request.param]
+    yield request.param
+    ops.SPLIT = old
+
+
 @pytest.fixture(scope="module")
 def P():
     assert torch.cuda.is_available()

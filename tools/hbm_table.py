@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Achieved HBM bandwidth per kernel: bytes per launch from the PMC passes (profiles/pmc_traffic.json, FETCH_SIZE x2 +
 WRITE_SIZE) divided by the average launch duration of the rocprofv3 --kernel-trace --stats run of the same command
-(profiles/r01_rocprofv3_bench_final/kernel_stats.csv).  Prints a markdown table."""
+(profiles/r01_rocprofv3_bench_split/kernel_stats.csv).  Prints a markdown table."""
 import csv
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
 stats = {}
-for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_rocprofv3_bench_final", "kernel_stats.csv"))):
+for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_rocprofv3_bench_split", "kernel_stats.csv"))):
     name = re.sub(r"^void ", "", row["Name"])
     name = re.sub(r"\(.*$", "", name)
     stats[name] = (int(row["Calls"]), float(row["AverageNs"]), float(row["Percentage"]))
