@@ -70,9 +70,9 @@ extern "C" int spk_bn_stats_partial(const float* x, float* partial, long long N,
 }
 
 // ---- finalize: partial [nblk][C][2] -> mean/invstd/scale/shift (+ running statistics) ---------------
-// Layer-1 convolutions emit ~25 k partial rows; a first stage folds them to <= 64 fp64 rows in parallel,
-// the second stage (one block per 32 channels) finishes in a fixed order.
-#define BN_STAGE_ROWS 64
+// Layer-1 convolutions emit ~100 k partial rows (25 MB); a first stage folds them to 256 fp64 rows in parallel
+// (256 x C/32 blocks), the second stage (one block per 32 channels) finishes in a fixed order.
+#define BN_STAGE_ROWS 256
 __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ partial, double* __restrict__ ws,
                                                                int nblk, int C) {
     __shared__ double red[8][32][2];
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __re
     double s = 0.0, ss = 0.0;
     if (ch < C) {
         for (int k = k0 + row; k < k1; k += 8) {
-            const float* p = partial + ((size_t)k * C + ch) * 2;
-            s += (double)p[0];
-            ss += (double)p[1];
+            const float2 p = *(const float2*)(partial + ((size_t)k * C + ch) * 2);
+            s += (double)p.x;
+            ss += (double)p.y;
         }
     }
     red[row][c][0] = s;

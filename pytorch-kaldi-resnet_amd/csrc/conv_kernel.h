@@ -4,20 +4,26 @@
 #ifndef STAGE_U
 #define STAGE_U 4   // staging loads in flight per thread
 #endif
+#ifndef STAGE_U2
+#define STAGE_U2 2  // pixels in flight per thread in the fused BatchNorm-backward staging (three loads each)
+#endif
 
 // SPLIT == 0: operands stay fp32 (v_mfma_f32_32x32x2_f32).  SPLIT == 6 / 9: every fp32 operand is split into three bf16
 // terms (x = x1 + x2 + x3 exactly: 3 x 8 significand bits) while it is staged (activations) or packed (weights), and the
 // product is formed from the 6 (or all 9) cross terms of weight >= 2^-16 (2^-24) on v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation: measured error against fp64 equals that of the native fp32 matrix instruction
 // (tools/probe/split_probe.hip), at 16/6 of its rate.
+#define SPK_SPLIT_CK 16   // channels per staged plane of the bf16-split kernels (32 = full 128-byte lines per pass was
+                          // measured 5 % slower: 208-byte LDS pixels force smaller tiles)
 template <int SPLIT>
 struct ConvCfg {
-    static constexpr int CK = SPLIT ? 16 : 32;   // channels per staged plane
+    static constexpr int CK = SPLIT ? SPK_SPLIT_CK : 32;   // channels per staged plane
     static constexpr int TPP = CK / 4;           // threads per staged pixel (one float4 of channels each)
     static constexpr int PPP = 256 / TPP;        // pixels per staging pass of the block
-    // LDS pixel pitch in 16-byte units: fp32 [32 ch + 4 pad] = 144 B; split [3 terms][16 ch bf16] + 16 pad = 112 B.  Both
-    // are odd multiples of 16 B, so the 8 lanes of a ds_read_b128 phase (consecutive pixels) hit distinct bank groups.
-    static constexpr int LP4 = SPLIT ? 7 : 9;
+    static constexpr int KG = CK / 16;           // split: 16-channel MFMA groups per plane
+    // LDS pixel pitch in 16-byte units: fp32 [32 ch + 4 pad] = 144 B; split [3 terms][CK ch bf16] + 16 pad = 112 / 208 B.
+    // All are odd multiples of 16 B, so the 8 lanes of a ds_read_b128 phase (consecutive pixels) hit distinct bank groups.
+    static constexpr int LP4 = SPLIT ? (3 * CK * 2 + 16) / 16 : 9;
 };
 
 struct ConvArgs {
@@ -117,10 +123,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         } else {
             uint2 t0, t1, t2;
             split3(w, t0, t1, t2);
-            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][16 ch]: 32 bytes per term
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][CK ch]: CK*2 bytes per term
             dst[0] = t0;
-            dst[4] = t1;
-            dst[8] = t2;
+            dst[CK / 4] = t1;
+            dst[CK / 2] = t2;
         }
     };
 
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const f32x4 k1 = *(const f32x4*)(a.in_coef + c), m1 = *(const f32x4*)(a.in_coef + a.Cin + c);
                 const f32x4 m2 = *(const f32x4*)(a.in_coef + 2 * a.Cin + c);
                 const bool owner = (cg == 0);
-                constexpr int U2 = 2;
+                constexpr int U2 = STAGE_U2;
                 for (int base = prow; base < halo_pix; base += PPP * U2) {
                     f32x4 v[U2], rw[U2], ac[U2];
                     bool inb[U2], core[U2];
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         } else {
             // ---- bf16-split K loop: one step = one (tap, 16-channel plane): 3 A reads per m-tile (one per term), 3 B loads
-            // per n-tile, SPLIT MFMAs per (m-tile, n-tile).  Both operand sets are prefetched one step ahead (ping-pong).
+            // per n-tile, SPLIT MFMAs per (m-tile, n-tile).
             const f32x4* lds4 = (const f32x4*)lds;
             // packed weights: [tap][Cin/16][term][Cout/32][64 lanes][8 bf16]
             const float* wbase = a.wpk + ((size_t)(ch * a.kc) * 3 * cout32 + cg * NT) * 256 + lane * 4;
@@ -321,57 +327,102 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             const size_t grp_stride = (size_t)3 * cout32 * 256;
             const size_t term_stride = (size_t)cout32 * 256;
             auto load_b = [&](f32x4 (*bf)[NT], int tw, int g) {
+#ifdef ABL_B_SAMEADDR
+                const float* wp = wbase + (size_t)(tw & 1) * tap_stride;   // diagnostic: a cache-hot address every step
+#else
                 const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
+#endif
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bf[s][j] = *(const f32x4*)(wp + s * term_stride + j * 256);
-            };
-            auto load_a = [&](f32x4 (*af)[MT], int toff4) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) af[s][i] = lds4[lbase[i] + toff4 + s * 2];
-            };
-            auto mma = [&](const f32x4 (*af)[MT], const f32x4 (*bf)[NT]) {
-                // cross terms by decreasing significance index sum: a_sa * b_sb has weight 2^(-8 (sa + sb))
-#pragma unroll
-                for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
-#pragma unroll
-                    for (int sa = 0; sa < 3; ++sa) {
-                        const int sb = sum - sa;
-                        if (sb < 0 || sb > 2) continue;
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[sa][i]),
-                                                                                   __builtin_bit_cast(bf16x8, bf[sb][j]),
-                                                                                   acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+#ifdef ABL_NO_BLOAD
+                        asm volatile("" : "+v"(bf[s][j]) : "s"(wp));
+#else
+                        bf[s][j] = *(const f32x4*)(wp + s * term_stride + j * 256);
+#endif
                     }
             };
-            f32x4 bq0[3][NT], bq1[3][NT], aq0[3][MT], aq1[3][MT];
-            load_b(bq0, a.tap_w[0], a.tap_g[0]);
-            __syncthreads();  // every wave is done reading the previous chunk's tile
-            stage_chunk(ch);
-            __syncthreads();
-            load_a(aq0, a.tap_off[0]);
-            int t = 0;
-            for (; t + 1 < a.ntaps; t += 2) {
-                // prefetches are unconditional (the last step re-fetches itself): branch-free body, counted waits
-                const int t2 = t + 2 < a.ntaps ? t + 2 : t + 1;
-                load_a(aq1, a.tap_off[t + 1]);
-                load_b(bq1, a.tap_w[t + 1], a.tap_g[t + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(aq0, bq0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_a(aq0, a.tap_off[t2]);
-                load_b(bq0, a.tap_w[t2], a.tap_g[t2]);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(aq1, bq1);
-                __builtin_amdgcn_sched_barrier(0);
+            auto load_a = [&](f32x4 (*af)[MT], int toff4, int g) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#ifdef ABL_NO_ALOAD
+                        asm volatile("" : "+v"(af[s][i]) : "s"(toff4 + g));
+#else
+                        af[s][i] = lds4[lbase[i] + toff4 + s * (CK / 8) + g * 2];
+#endif
+                    }
+            };
+            {
+                // Three-deep operand pipeline.  A step (one tap of a 16-channel plane) is only 6*MT*NT MFMAs of 32 cycles -
+                // about half a microsecond, less than an L2 round trip - so the B fragments are requested TWO steps
+                // ahead (three register buffers in rotation), while the A fragments (LDS, ~100 cycles) roll inside one
+                // buffer: as soon as the MFMAs of m-tile i have issued, the next step's fragments of that m-tile are read
+                // into the same registers.  Tap-table entries (scalar loads) are fetched three steps early.
+                f32x4 b0[3][NT], b1[3][NT], b2[3][NT], aq[3][MT];
+#if defined(ABL_NO_BLOAD) || defined(ABL_NO_ALOAD)
+                for (int s = 0; s < 3; ++s) {
+                    for (int j = 0; j < NT; ++j) b0[s][j] = b1[s][j] = b2[s][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
+                    for (int i = 0; i < MT; ++i) aq[s][i] = (f32x4){1.f, 2.f, 3.f, 4.f};
+                }
+#endif
+                const int last = a.ntaps - 1;
+                auto step = [&](const f32x4 (*bc)[NT], f32x4 (*bn)[NT], int o_next, int w_n2, int g_n2) {
+                    load_b(bn, w_n2, g_n2);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+#pragma unroll
+                            for (int sa = 0; sa < 3; ++sa) {
+                                const int sb = sum - sa;
+                                if (sb < 0 || sb > 2) continue;
+#pragma unroll
+                                for (int j = 0; j < NT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[sa][i]),
+                                                                                       __builtin_bit_cast(bf16x8, bc[sb][j]),
+                                                                                       acc[i][j], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+#ifdef ABL_NO_ALOAD
+                            asm volatile("" : "+v"(aq[s][i]) : "s"(o_next));
+#else
+                            aq[s][i] = lds4[lbase[i] + o_next + s * (CK / 8)];
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                load_b(b0, a.tap_w[0], a.tap_g[0]);
+                __syncthreads();  // every wave is done reading the previous chunk's tile
+                stage_chunk(ch);
+                __syncthreads();
+                load_b(b1, a.tap_w[min(1, last)], a.tap_g[min(1, last)]);   // (after staging: its registers are busy there)
+                load_a(aq, a.tap_off[0], 0);
+                int o1 = a.tap_off[min(1, last)], w2 = a.tap_w[min(2, last)], g2 = a.tap_g[min(2, last)];
+                int t = 0;
+                for (; t + 2 < a.ntaps; t += 3) {
+                    const int i2 = min(t + 2, last), i3 = min(t + 3, last), i4 = min(t + 4, last), i5 = min(t + 5, last);
+                    const int o2 = a.tap_off[i2], w3 = a.tap_w[i3], g3 = a.tap_g[i3];
+                    const int o3 = a.tap_off[i3], w4 = a.tap_w[i4], g4 = a.tap_g[i4];
+                    const int o4 = a.tap_off[i4], w5 = a.tap_w[i5], g5 = a.tap_g[i5];
+                    step(b0, b2, o1, w2, g2);
+                    step(b1, b0, o2, w3, g3);
+                    step(b2, b1, o3, w4, g4);
+                    o1 = o4;
+                    w2 = w5;
+                    g2 = g5;
+                }
+                if (t < a.ntaps) {      // one or two steps left: they are in b0 (and b1); prefetches re-fetch the last tap
+                    step(b0, b2, o1, w2, g2);
+                    if (t + 1 < a.ntaps) step(b1, b0, a.tap_off[last], a.tap_w[last], a.tap_g[last]);
+                }
             }
-            if (t < a.ntaps) mma(aq0, bq0);   // odd number of steps: the last one is already in the "0" registers
         }
     }
 

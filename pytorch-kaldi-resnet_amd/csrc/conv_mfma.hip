@@ -49,8 +49,8 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(NT >= 1 && Cout % (32 * NT) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT (NT=%d)", Cout, NT);
     SPK_REQUIRE(ntaps >= 1 && ntaps <= 9, "spk_conv_mfma: ntaps=%d out of range", ntaps);
     SPK_REQUIRE(split == 0 || split == 6 || split == 9, "spk_conv_mfma: split=%d (0 = fp32 operands, 6 / 9 = bf16 cross terms)", split);
-    const int ck = split ? 16 : 32;        // channels per staged plane
-    const int lp4 = split ? 7 : 9;         // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
+    const int ck = split ? SPK_SPLIT_CK : 32;                     // channels per staged plane
+    const int lp4 = split ? (3 * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
     SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
     SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT, "spk_conv_mfma: tile %dx%d exceeds 128*MT (MT=%d)", TH, TW, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
@@ -101,7 +101,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
             const int t = tt % ntaps, pl = tt / ntaps;
             a.tap_off[tt] = sp_off[t] + pl * plane4;
             a.tap_w[tt] = sp_w[t];
-            a.tap_g[tt] = pl * (split ? 1 : 4);
+            a.tap_g[tt] = pl * (split ? SPK_SPLIT_CK / 16 : 4);
         }
     }
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);

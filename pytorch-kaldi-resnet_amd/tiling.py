@@ -9,6 +9,7 @@ import os as _os
 from functools import lru_cache
 
 LDS_PIX_BYTES = 144
+SPLIT_PIX_BYTES = int(_os.environ.get('SPK_SPLIT_PIX_BYTES', '112'))   # LDS bytes per pixel of the bf16-split kernels (csrc/conv_kernel.h)
 LDS_SOFT = 52 * 1024      # 3 blocks / CU
 LDS_HARD = 80 * 1024      # 2 blocks / CU
 
@@ -47,7 +48,7 @@ AUTOTUNE = _os.environ.get("SPK_AUTOTUNE", "0") == "1"
 def conv_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_config=3, split=0):
     """Candidate (TH, TW, MT, NT) tiles: for every register configuration the best-utilised few shapes."""
     cands = []
-    pix_bytes = 112 if split else LDS_PIX_BYTES
+    pix_bytes = SPLIT_PIX_BYTES if split else LDS_PIX_BYTES
     for MT in (1, 2, 3, 4):
         cap = 128 * MT
         for NT in (1, 2, 4):
