@@ -237,3 +237,32 @@ def test_tile_selection_invariants(shape):
         assert hip.lib().spk_conv_wgrad_limits(WN, ctypes.byref(mh), ctypes.byref(mt)) == 0
         assert ((TH - 1) * s + k) * ((TW - 1) * s + k) <= mh.value == tiling.WGRAD_MAX_HALO
         assert TH * TW <= mt.value == tiling.WGRAD_MAX_TILE[WN]
+
+
+def test_tile_lookup_by_mode_and_operand_mode(monkeypatch):
+    """Host-side tile selection: the measured table wins over the heuristic, the fused-BN-backward mode and the
+    bf16-split operand mode have their own keys with fall-back to the plain entry, every result fits the kernel limits."""
+    from pytorch_kaldi_resnet_amd import tiling
+    key = (20, 75, 1, 3, 3, 9, 128)
+    assert tiling.conv_tile(*key) == tiling.FORCE_CONV[key]
+    assert tiling.conv_tile(*key, mode=1) == tiling.FORCE_CONV.get(key + (1,), tiling.FORCE_CONV[key])
+    assert tiling.conv_tile(*key, split=6) == tiling.FORCE_CONV_SPLIT.get(key, tiling.FORCE_CONV[key])
+    monkeypatch.setitem(tiling.FORCE_CONV_SPLIT, key, (10, 25, 2, 2))
+    monkeypatch.setitem(tiling.FORCE_CONV_SPLIT, key + (1,), (5, 25, 1, 2))
+    assert tiling.conv_tile(*key, split=6) == (10, 25, 2, 2)
+    assert tiling.conv_tile(*key, mode=1, split=6) == (5, 25, 1, 2)
+    assert tiling.conv_tile(*key) == tiling.FORCE_CONV[key]
+    for shape in [(7, 9, 1, 3, 3, 9, 32), (33, 77, 2, 3, 3, 9, 64), (5, 3, 1, 1, 1, 1, 256), (80, 401, 1, 3, 3, 9, 32)]:
+        TH, TW, MT, NT = tiling.conv_tile(*shape)
+        assert TH * TW <= 128 * MT and shape[6] % (32 * NT) == 0
+        halo = ((TH - 1) * shape[2] + shape[3]) * ((TW - 1) * shape[2] + shape[4])
+        assert halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD
+    for c in tiling.conv_candidates(20, 75, 1, 3, 3, 9, 128, split=6):
+        assert (c[2], c[3]) in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2), (1, 4))
+
+
+def test_operand_modes_are_declared():
+    from pytorch_kaldi_resnet_amd import ops
+    assert ops.MFMA_MODES == {"f32": 0, "bf16x6": 6, "bf16x9": 9}
+    assert ops.SPLIT in ops.MFMA_MODES.values()
+    assert ops.split_for(1) == 0 and ops.split_for(3) == ops.SPLIT      # 1x1 convolutions always use fp32 operands
