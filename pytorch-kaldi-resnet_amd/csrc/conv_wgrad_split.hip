@@ -21,7 +21,7 @@ static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int WK, int WN, int SPLIT>
+template <int WK, int WN, int SPLIT, int NX>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int NTAPS = 9;
@@ -48,14 +48,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     const int quad = tid & 7;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (flags & SPK_IN_AFFINE_RELU) {
-        sc = *(const f32x4*)(a.in_scale + ci0 + quad * 4);
-        sh = *(const f32x4*)(a.in_shift + ci0 + quad * 4);
-    }
 
     // region pipeline as in conv_wgrad.hip: next region's global loads fly during this region's MFMAs
-    constexpr int NX = WGRAD_NX, ND = WGRAD_ND;
+    constexpr int ND = WGRAD_ND;   // NX (X-halo float4 per thread) is a template parameter: 4 when the halo fits 128 pixels
     constexpr int QPP = WN * 8;
     constexpr int PSTEP = 256 / QPP;
     const int cq = tid % QPP;
@@ -96,6 +91,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
         }
     };
     auto publish = [&]() {      // registers -> three bf16 terms in LDS (zero outside the image / tile; fused BN+ReLU on X)
+        // the BN coefficients are re-read here (L1-resident) rather than held in registers across the MFMA loop
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (flags & SPK_IN_AFFINE_RELU) {
+            sc = *(const f32x4*)(a.in_scale + ci0 + quad * 4);
+            sh = *(const f32x4*)(a.in_shift + ci0 + quad * 4);
+        }
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             const int p = (tid >> 3) + 32 * u;
@@ -235,10 +236,14 @@ static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(split): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
-    if (split == 6)
-        hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6>), grid, dim3(256), lds_bytes, st, a);
-    else
-        hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9>), grid, dim3(256), lds_bytes, st, a);
+    const bool small = a.halo_h * a.halo_w <= 32 * 4;
+    if (split == 6) {
+        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, 4>), grid, dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+    } else {
+        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9, 4>), grid, dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+    }
     SPK_LAUNCH_CHECK("spk_conv_wgrad(split)");
     return 0;
 }
