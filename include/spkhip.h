@@ -48,6 +48,11 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
 /* the same weights for the bf16-split operand mode of spk_conv_mfma (split = 6 or 9): every weight as three bf16 terms
  * whose sum is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight */
 int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
+/* every convolution of the network in one launch: `jobs` is a device array of njobs 48-byte entries
+ * { const float* w; void* wpk; int Cout, Cin, KH*KW, transpose, split, total = Cout*Cin*KH*KW, block0, pad; } ordered by
+ * block0 (first 256-thread block of the job; total_blocks = sum of ceil(total/256)).  spk_pack_job_bytes() = 48. */
+int spk_pack_job_bytes(void);
+int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, void* stream);
 
 /* Implicit-GEMM convolution described by a tap table; replaces F.conv2d forward (scripts/model.py:51,56,
  * 118,122,126,58-59) and, with a transposed pack and mirrored taps, its data gradient (autograd of the same,

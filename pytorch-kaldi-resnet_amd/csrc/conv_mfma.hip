@@ -122,35 +122,3 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     spk_set_error("spk_conv_mfma: unsupported tile config MT=%d NT=%d", MT, NT);
     return -1;
 }
-
-// ---- weight packing -------------------------------------------------------------------------
-// OIHW [Cout][Cin][KH][KW] -> [tap][K/8][N/32][64][4].  transpose == 0: K = cin, N = cout (forward);
-// transpose == 1: K = cout, N = cin (data gradient).  Tap index t = kh*KW + kw in both cases.
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
-                                        int KHW, int transpose, int total) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
-    int i = idx;
-    const int s = i & 3; i >>= 2;
-    const int lane = i & 63; i >>= 6;
-    const int nt = i % (N >> 5); i /= (N >> 5);
-    const int g = i % (K >> 3);
-    const int t = i / (K >> 3);
-    const int n = nt * 32 + (lane & 31);
-    const int k = g * 8 + (lane >> 5) * 4 + s;
-    const int co = transpose ? k : n, ci = transpose ? n : k;
-    wpk[idx] = w[((size_t)co * Cin + ci) * KHW + t];
-}
-
-extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose,
-                                    void* stream) {
-    SPK_REQUIRE(w && wpk, "spk_pack_conv_weight: null pointer");
-    SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight: channels (%d,%d) must be multiples of 32", Cout, Cin);
-    SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight: kernel %dx%d unsupported", KH, KW);
-    const int total = Cout * Cin * KH * KW;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       wpk, Cout, Cin, KH * KW, transpose, total);
-    SPK_LAUNCH_CHECK("spk_pack_conv_weight");
-    return 0;
-}

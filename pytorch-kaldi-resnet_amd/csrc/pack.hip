@@ -1,0 +1,119 @@
+// Weight packing for the matrix-core convolutions: nn.Conv2d OIHW fp32 weights -> MFMA B-fragment order, once per step
+// for the forward (K = Cin) and once transposed for the data gradient (K = Cout).
+//   fp32 operands : [tap][K/8][N/32][64 lanes][4 floats]      lane l: n = 32 nt + (l & 31), k = 8 g + 4 (l >> 5) + {0..3}
+//   bf16 split    : [tap][K/16][term 0..2][N/32][64 lanes][8 bf16]  lane l: n as above, k = 16 g + 8 (l >> 5) + {0..7};
+//                   term s of a weight is the s-th bf16 of its exact three-term split (w = t0 + t1 + t2)
+// spk_pack_conv_weights_batched packs every convolution of the network in ONE launch from a device-resident job table
+// (the weights change every step, so this runs once per step: 70 tiny launches become one).
+#include "spk_common.h"
+
+static __device__ __forceinline__ void pack_f32_elem(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
+                                                     int KHW, int transpose, int idx) {
+    const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+    int i = idx;
+    const int s = i & 3; i >>= 2;
+    const int lane = i & 63; i >>= 6;
+    const int nt = i % (N >> 5); i /= (N >> 5);
+    const int g = i % (K >> 3);
+    const int t = i / (K >> 3);
+    const int n = nt * 32 + (lane & 31);
+    const int k = g * 8 + (lane >> 5) * 4 + s;
+    const int co = transpose ? k : n, ci = transpose ? n : k;
+    wpk[idx] = w[((size_t)co * Cin + ci) * KHW + t];
+}
+
+static __device__ __forceinline__ void pack_split_elem(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout,
+                                                       int Cin, int KHW, int transpose, int idx) {
+    const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+    int i = idx;
+    const int e = i & 7; i >>= 3;
+    const int lane = i & 63; i >>= 6;
+    const int nt = i % (N >> 5); i /= (N >> 5);
+    const int g = i % (K >> 4);
+    const int t = i / (K >> 4);
+    const int n = nt * 32 + (lane & 31);
+    const int k = g * 16 + (lane >> 5) * 8 + e;
+    const int co = transpose ? k : n, ci = transpose ? n : k;
+    float x = w[((size_t)co * Cin + ci) * KHW + t];
+    const size_t term = (size_t)(N >> 5) * 512;
+    const size_t o = ((((size_t)t * (K >> 4) + g) * 3) * (N >> 5) + nt) * 512 + lane * 8 + e;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const __bf16 b = (__bf16)x;
+        wpk[o + s * term] = __builtin_bit_cast(unsigned short, b);
+        x -= (float)b;
+    }
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int KHW,
+                                        int transpose, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_f32_elem(w, wpk, Cout, Cin, KHW, transpose, idx);
+}
+
+__global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
+                                              int KHW, int transpose, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_split_elem(w, wpk, Cout, Cin, KHW, transpose, idx);
+}
+
+extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose,
+                                    void* stream) {
+    SPK_REQUIRE(w && wpk, "spk_pack_conv_weight: null pointer");
+    SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight: channels (%d,%d) must be multiples of 32", Cout, Cin);
+    SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight: kernel %dx%d unsupported", KH, KW);
+    const int total = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wpk, Cout, Cin, KH * KW, transpose, total);
+    SPK_LAUNCH_CHECK("spk_pack_conv_weight");
+    return 0;
+}
+
+extern "C" int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose,
+                                          void* stream) {
+    SPK_REQUIRE(w && wpk, "spk_pack_conv_weight_split: null pointer");
+    SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight_split: channels (%d,%d) must be multiples of 32", Cout, Cin);
+    SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight_split: kernel %dx%d unsupported", KH, KW);
+    const int total = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)wpk, Cout, Cin, KH * KW, transpose, total);
+    SPK_LAUNCH_CHECK("spk_pack_conv_weight_split");
+    return 0;
+}
+
+// ---- all convolutions in one launch -------------------------------------------------------------------------------
+// Job table entry (device memory, 48 bytes; layout mirrored by ops.py with struct.pack("<QQ8i")).
+struct PackJob {
+    const float* w;     // OIHW weights
+    void* wpk;          // destination
+    int Cout, Cin, KHW, transpose;
+    int split;          // 0 = fp32 fragment order, otherwise the three-term bf16 order
+    int total;          // Cout*Cin*KHW elements = threads of this job
+    int block0;         // first block of this job (jobs are ordered; block0 of job i+1 = block0 + ceil(total/256))
+    int pad;
+};
+
+__global__ void pack_conv_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                       // last job whose block0 <= b (uniform per block: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int idx = (b - j.block0) * 256 + threadIdx.x;
+    if (idx >= j.total) return;
+    if (j.split) pack_split_elem(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
+    else pack_f32_elem(j.w, (float*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
+}
+
+extern "C" int spk_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+
+extern "C" int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, void* stream) {
+    SPK_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "spk_pack_conv_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_conv_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs);
+    SPK_LAUNCH_CHECK("spk_pack_conv_weights_batched");
+    return 0;
+}

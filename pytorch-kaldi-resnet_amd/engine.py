@@ -29,6 +29,21 @@ class _Conv:
         if need_t:
             self.wpk_t = ops.pack_conv_weight(w, True, self.wpk_t)
 
+    def pack_jobs(self, need_t):
+        """(weight, packed buffer, transpose) entries for the batched pack; allocates the packed buffers on first use."""
+        w = self.h.weight.data
+        if self.cin == 1:
+            return []
+        n = ops.packed_numel(w)
+        if self.wpk is None or self.wpk.numel() != n:
+            self.wpk = torch.empty(n, device=w.device, dtype=torch.float32)
+        jobs = [(w, self.wpk, False)]
+        if need_t:
+            if self.wpk_t is None or self.wpk_t.numel() != n:
+                self.wpk_t = torch.empty(n, device=w.device, dtype=torch.float32)
+            jobs.append((w, self.wpk_t, True))
+        return jobs
+
 
 class _BN:
     def __init__(self, holder):
@@ -96,6 +111,7 @@ class Engine:
         self.pool_mode = 1 if model.pooling == "mean+std" else 0
         self.dirty = True
         self._packed_for_bwd = False
+        self._pack_tables = {}
         # weight gradients (compute-bound, off the critical path) run on a side stream so that they overlap the
         # HBM-bound BatchNorm-backward passes of the main dgrad chain
         self.wgrad_stream = None
@@ -118,8 +134,15 @@ class Engine:
     def _repack(self, need_t):
         if not self.dirty and (self._packed_for_bwd or not need_t):
             return
-        for c in self._all_convs():
-            c.repack(need_t)
+        # one launch packs every convolution (forward order, plus the transposed order the backward needs); the job
+        # table lives on the device and is rebuilt only when a buffer, the operand mode or need_t changes
+        jobs = [j for c in self._all_convs() for j in c.pack_jobs(need_t)]
+        key = [(w.data_ptr(), p.data_ptr(), t, ops.split_for(w.shape[2])) for w, p, t in jobs]
+        tab = self._pack_tables.get(need_t)
+        if tab is None or tab.key != key:
+            assert not torch.cuda.is_current_stream_capturing() or tab is None, "pack table changed during graph capture"
+            tab = self._pack_tables[need_t] = ops.PackTable(jobs, jobs[0][0].device)
+        tab.run()
         self.dirty = False
         self._packed_for_bwd = need_t
 
@@ -416,13 +439,16 @@ class GraphedTrainStep:
     gradients land in the model's flat gradient arena exactly as in the eager path (always overwritten).
     The optimizer step stays outside the graph (its learning rate changes per epoch)."""
 
-    def __init__(self, engine, batch, frames, warmup=2):
+    def __init__(self, engine, batch, frames, warmup=2, side_stream=None):
+        import os
+        if side_stream is None:
+            side_stream = os.environ.get("SPK_GRAPH_SIDE", "0") == "1"
         m = engine.m
         dev = m.flat_parameters().device
         self.eng = engine
         # measured on MI355X / ROCm 7.2: a captured two-branch graph (weight gradients on the side stream) replays
         # ~2 % slower than the same kernels captured on one stream, so the graph is recorded single-stream
-        side, engine.use_side_stream = engine.use_side_stream, False
+        side, engine.use_side_stream = engine.use_side_stream, bool(side_stream)
         self.x = torch.zeros(batch, m.feat_dim, frames, device=dev)
         self.y = torch.zeros(batch, dtype=torch.long, device=dev)
         self.shape = (batch, m.feat_dim, frames)

@@ -21,6 +21,8 @@ _IP = ctypes.POINTER(ctypes.c_int)
 _SIGS = {
     "spk_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_pack_conv_weight_split": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "spk_pack_job_bytes": [],
+    "spk_pack_conv_weights_batched": [_P, _I, _I, _P],
     "spk_conv_mfma": [_P] * 18 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 16 + [_P],
     "spk_conv_wgrad_limits": [_I, _IP, _IP],

@@ -65,6 +65,35 @@ def pack_conv_weight(w, transpose=False, out=None):
     return out
 
 
+def packed_numel(w):
+    """floats of the packed form of an OIHW weight in the current operand mode."""
+    return w.numel() * 3 // 2 if split_for(w.shape[2]) else w.numel()
+
+
+class PackTable:
+    """Device-resident job table for spk_pack_conv_weights_batched: (weight, packed buffer, transpose) triples of every
+    convolution, packed by ONE launch per step.  Rebuilt by the engine whenever a buffer or the operand mode changes."""
+
+    def __init__(self, jobs, device):
+        import struct
+        assert hip.lib().spk_pack_job_bytes() == 48
+        blob, block0 = b"", 0
+        self.key = []
+        for w, wpk, transpose in jobs:
+            Cout, Cin, KH, KW = w.shape
+            split = split_for(KH)
+            assert wpk.numel() == packed_numel(w) and w.is_contiguous()
+            blob += struct.pack("<QQ8i", w.data_ptr(), wpk.data_ptr(), Cout, Cin, KH * KW, 1 if transpose else 0, split,
+                                w.numel(), block0, 0)
+            block0 += (w.numel() + 255) // 256
+            self.key.append((w.data_ptr(), wpk.data_ptr(), transpose, split))
+        self.njobs, self.blocks = len(jobs), block0
+        self.table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+
+    def run(self):
+        call("spk_pack_conv_weights_batched", ptr(self.table), self.njobs, self.blocks, stream(), label="spk_pack_conv_weight")
+
+
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
                  bn_bwd=None, in_bnbwd=None, side=None, split=0):
     B, IH, IW, Cin = x.shape

@@ -169,6 +169,24 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     assert e < 3e-5, "wgrad accumulate %g" % e
 
 
+def test_batched_weight_pack_equals_per_conv_pack(ops, mfma_mode):
+    """spk_pack_conv_weights_batched (one launch for the whole network) against the per-convolution exports, both operand
+    modes, mixed shapes, forward and transposed orders: bit-identical buffers."""
+    torch.manual_seed(3)
+    ws = [torch.randn(co, ci, k, k, device="cuda") for co, ci, k in ((32, 32, 3), (64, 32, 3), (64, 32, 1), (128, 64, 3), (256, 256, 3), (256, 128, 1))]
+    jobs, refs = [], []
+    for w in ws:
+        for tr in (False, True):
+            buf = torch.full((ops.packed_numel(w),), float("nan"), device="cuda")
+            jobs.append((w, buf, tr))
+            refs.append(ops.pack_conv_weight(w, tr))
+    tab = ops.PackTable(jobs, "cuda")
+    tab.run()
+    torch.cuda.synchronize()
+    for (w, buf, tr), ref in zip(jobs, refs):
+        assert torch.equal(buf.view(torch.int32), ref.view(torch.int32)), (tuple(w.shape), tr)
+
+
 def test_split_operands_are_as_accurate_as_fp32_operands(ops):
     """The bf16-split operand modes against an fp64 convolution on inputs with a wide dynamic range (exp(3 N(0,1))
     magnitudes: 6 decades) and on ReLU-like activations, for forward, data gradient and weight gradient: the rms error
