@@ -343,10 +343,10 @@ _ws64_cache = {}
 
 
 def _ws64(device):
-    """fp64 scratch for the two-stage BN finalize: 64 rows x 1024 channels x 2 doubles is the maximum."""
+    """fp64 scratch of the two-stage BN finalize (spk_bn_finalize_workspace: 256 rows x C x 2 doubles; sized for C = 2048)."""
     w = _ws64_cache.get(str(device))
     if w is None:
-        w = torch.empty(64 * 1024 * 2, device=device, dtype=torch.float64)
+        w = torch.zeros(256 * 2048 * 2 + 64, device=device, dtype=torch.float64)
         _ws64_cache[str(device)] = w
     return w
 

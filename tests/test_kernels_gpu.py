@@ -169,6 +169,46 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     assert e < 3e-5, "wgrad accumulate %g" % e
 
 
+@pytest.mark.parametrize("C,rows", [(32, 97280), (256, 4100), (64, 1025), (96, 1500)])
+def test_bn_finalize_many_partial_rows(ops, C, rows):
+    """The two-stage fold + finalize path (more than 1024 partial rows: conv-epilogue statistics of the big layers):
+    values against fp64 sums, bitwise repeatability, and reuse of the shared fp64 workspace by back-to-back launches
+    with different data and different channel counts."""
+    rng = np.random.RandomState(C + rows)
+    count = float(rows * 37)
+    outs = []
+    for rep in range(3):
+        part = torch.from_numpy((rng.randn(rows, C, 2) * (1.0 + rep)).astype(np.float32))
+        part[:, :, 1] = part[:, :, 1].abs() * 40 + 5                      # sum of squares side: keep the variance positive
+        gamma = torch.from_numpy(rng.rand(C).astype(np.float32) + 0.5)
+        beta = torch.from_numpy(rng.randn(C).astype(np.float32))
+        s = part.double().sum(0)
+        mean = s[:, 0] / count
+        var = (s[:, 1] / count - mean * mean).clamp_min(0)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        for again in range(2):
+            bn4 = torch.zeros(4, C, device="cuda")
+            rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+            nbt = torch.zeros((), dtype=torch.long, device="cuda")
+            ops.bn_finalize(part.cuda(), count, gamma.cuda(), beta.cuda(), rm, rv, nbt, bn4)
+            dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+            coef = ops.bn_bwd_coef(part.cuda(), count, gamma.cuda(), bn4, dg, db)
+            torch.cuda.synchronize()
+            outs.append((rep, bn4.cpu(), rm.cpu(), rv.cpu(), dg.cpu(), db.cpu(), coef.cpu()))
+            assert int(nbt) == 1
+        a, b = outs[-2], outs[-1]
+        for u, v in zip(a[1:], b[1:]):
+            assert torch.equal(u, v)
+        bn4c = b[1].double()
+        np.testing.assert_allclose(bn4c[0].numpy(), mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(bn4c[1].numpy(), invstd.numpy(), rtol=2e-6)
+        np.testing.assert_allclose(bn4c[2].numpy(), (gamma.double() * invstd).numpy(), rtol=3e-6)
+        np.testing.assert_allclose(b[3].numpy(), (0.9 + 0.1 * var * count / (count - 1)).numpy(), rtol=1e-5)
+        np.testing.assert_allclose(b[5].numpy(), s[:, 0].numpy(), rtol=1e-6, atol=1e-3)      # dbeta = sum of column 0
+        np.testing.assert_allclose(b[4].numpy(), s[:, 1].numpy(), rtol=1e-6)                 # dgamma = sum of column 1
+        np.testing.assert_allclose(b[6][1].numpy(), (s[:, 0] / count).numpy(), rtol=1e-6, atol=1e-7)
+
+
 def test_batched_weight_pack_equals_per_conv_pack(ops, mfma_mode):
     """spk_pack_conv_weights_batched (one launch for the whole network) against the per-convolution exports, both operand
     modes, mixed shapes, forward and transposed orders: bit-identical buffers."""
