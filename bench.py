@@ -37,7 +37,7 @@ def mfma_peak(kernel_label):
     terms = 0
     if kernel_label.startswith("conv_mfma_kernel") and len(inner) == 4:
         terms = int(inner[3])
-    elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 3:
+    elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 4:
         terms = int(inner[2])
     if terms:
         return PEAK_BF16_MFMA_TFLOPS / terms, "bf16 dense peak / %d cross products per fp32 multiply-add" % terms
@@ -276,10 +276,20 @@ def main():
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         eng.use_side_stream = True
+        # an event pair around NOTHING still measures the marker packets themselves (tens of microseconds on ROCm):
+        # calibrate that bracket overhead on the same stream and subtract it from every bracketed launch
+        empty = []
+        for _ in range(64):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            a1.record()
+            empty.append((a0, a1))
+        torch.cuda.synchronize()
+        overhead_ms = sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
         agg = {}
         for name, flops, e0, e1 in recs:
             a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[0] += max(e0.elapsed_time(e1) - overhead_ms, 1e-3) * 1e-3
             a[1] += flops
             a[2] += 1
         name, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
@@ -297,6 +307,7 @@ def main():
                     "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                     "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                    "event_bracket_overhead_us": round(overhead_ms * 1e3, 1),
                     "gflop_per_launch": round(fsum / n / 1e9, 3),
                     "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
                                         "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,

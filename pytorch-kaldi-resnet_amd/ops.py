@@ -303,7 +303,8 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split_for(ksize),
          stream(),
-         label=("conv_wgrad_split_kernel<%d,%d,%d>" % (4 // WN, WN, split_for(ksize))) if split_for(ksize)
+         label=("conv_wgrad_split_kernel<%d,%d,%d,%d>" % (
+             4 // WN, WN, split_for(ksize), 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split_for(ksize)
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
