@@ -70,7 +70,9 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * (planes are then 16 channels: Cin % (16*kc) == 0). */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
-                  const float* in_act, const float* in_bn4, const float* in_coef, float* side_draw, float* side_dz,
+                  const float* in_act, const float* in_bn4, const float* in_coef, const unsigned* in_mask /* sign bits of
+                  in_act, [pixel][Cin/32] words: read instead of it */, const unsigned* bn_mask /* same for bn_act,
+                  [pixel][Cout/32] */, float* side_draw, float* side_dz,
                   const float* bn_raw, const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
@@ -116,9 +118,11 @@ int spk_bn_finalize(const float* partial, int nblk, int C, double count, const f
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int C, float eps, void* stream);
-/* out = [relu](raw*scale + shift [+ res | + res*res_scale + res_shift])  (BasicBlock tail, scripts/model.py:58-62) */
+/* out = [relu](raw*scale + shift [+ res | + res*res_scale + res_shift])  (BasicBlock tail, scripts/model.py:58-62).
+ * mask_out (optional, C % 32 == 0): sign bits of `out`, one uint32 per 32 channels of a pixel ([N][C/32]); the backward
+ * kernels read these bits (spk_conv_mfma in_mask / bn_mask) instead of the activated tensor. */
 int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
-                 const float* res_shift, float* out, long long N, int C, int relu, void* stream);
+                 const float* res_shift, float* out, unsigned* mask_out, long long N, int C, int relu, void* stream);
 /* backward; mask_mode 0: dz = dy, 1: dz = dy*(act > 0), 2: dz = dy*(raw*scale+shift > 0) */
 int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,

@@ -201,7 +201,8 @@ extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                       float* __restrict__ out, long long nquads, int C, int relu) {
+                                                       float* __restrict__ out, unsigned* __restrict__ mask_out, long long nquads,
+                                                       int C, int relu) {
     const int cmask = C - 1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
         const int c = (int)((i * 4) & cmask);
@@ -219,6 +220,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             v[3] = fmaxf(v[3], 0.f);
         }
         *(f32x4*)(out + i * 4) = v;
+        if (mask_out) {
+            // sign mask of the output, one bit per value, 32 channels per word: the backward pass reads these bits instead
+            // of the whole activated tensor.  Eight consecutive lanes hold the 32 channels of one word (C % 32 == 0, the
+            // grid stride is a multiple of the wave size: the eight lanes are always active together).
+            unsigned bits = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+            bits <<= 4 * (threadIdx.x & 7);
+            bits |= __shfl_xor(bits, 1, 64);
+            bits |= __shfl_xor(bits, 2, 64);
+            bits |= __shfl_xor(bits, 4, 64);
+            if ((threadIdx.x & 7) == 0) mask_out[i >> 3] = bits;
+        }
     }
 }
 
@@ -229,15 +241,16 @@ static int stream_grid(long long nquads) {
 }
 
 extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res,
-                            const float* res_scale, const float* res_shift, float* out, long long N, int C, int relu,
-                            void* stream) {
+                            const float* res_scale, const float* res_shift, float* out, unsigned* mask_out, long long N, int C,
+                            int relu, void* stream) {
     SPK_REQUIRE(raw && scale && shift && out, "spk_bn_apply: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_apply: N=%lld C=%d", N, C);
     SPK_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), "spk_bn_apply: residual affine must come in pairs");
     SPK_REQUIRE(!res_scale || res, "spk_bn_apply: residual affine without residual");
+    SPK_REQUIRE(!mask_out || C % 32 == 0, "spk_bn_apply: the sign mask needs C %% 32 == 0 (C=%d)", C);
     const long long nquads = N * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res,
-                       res_scale, res_shift, out, nquads, C, relu);
+                       res_scale, res_shift, out, mask_out, nquads, C, relu);
     SPK_LAUNCH_CHECK("spk_bn_apply");
     return 0;
 }

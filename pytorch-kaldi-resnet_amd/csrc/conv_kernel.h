@@ -39,6 +39,8 @@ struct ConvArgs {
     const float* in_act;   //   its activated output (mask = act > 0) or NULL (mask = raw*scale+shift > 0),
     const float* in_bn4;   //   [4][Cin]: mean, invstd, scale, shift,
     const float* in_coef;  //   [3][Cin]: gamma*invstd, mean(dz), mean(dz*xhat)  (spk_bn_bwd_finalize)
+    const unsigned* in_mask;   //   alternative to in_act: its sign bits, [pixel][Cin/32] words (spk_bn_apply mask_out)
+    const unsigned* bn_mask;   // SPK_EPI_BNBWD: alternative to bn_act, [pixel][Cout/32] words
     float* side_draw;      //   optional side outputs of the tile's own pixels: the transformed value (gradient wrt the raw
     float* side_dz;        //   conv output, consumed by the weight gradient) and dz = in*mask (the shortcut gradient)
     const float* bn_raw;   // SPK_EPI_BNBWD: raw conv output of the BatchNorm whose backward statistics are reduced here
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 constexpr int U2 = STAGE_U2;
                 for (int base = prow; base < halo_pix; base += PPP * U2) {
                     f32x4 v[U2], rw[U2], ac[U2];
+                    unsigned mw[U2];
                     bool inb[U2], core[U2];
                     size_t off[U2];
 #pragma unroll
@@ -169,15 +172,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         off[u] = (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c;
                         v[u] = *(const f32x4*)(a.in + off[u]);
                         rw[u] = *(const f32x4*)(a.in_raw + off[u]);
-                        if (a.in_act) ac[u] = *(const f32x4*)(a.in_act + off[u]);
+                        if (a.in_mask) mw[u] = a.in_mask[(size_t)((b * a.IH + cy) * a.IW + cx) * (a.Cin >> 5) + (c >> 5)];
+                        else if (a.in_act) ac[u] = *(const f32x4*)(a.in_act + off[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < U2; ++u) {
                         const int p = base + PPP * u;
-                        const f32x4 m = a.in_act ? ac[u] : rw[u] * bsc + bsh;
                         f32x4 dz;
+                        if (a.in_mask) {
+                            const unsigned bits = mw[u] >> (c & 31);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[u][k] : 0.f;
+                            for (int k = 0; k < 4; ++k) dz[k] = ((bits >> k) & 1u) ? v[u][k] : 0.f;
+                        } else {
+                            const f32x4 m = a.in_act ? ac[u] : rw[u] * bsc + bsh;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[u][k] : 0.f;
+                        }
                         f32x4 w = k1 * (dz - m1 - ((rw[u] - mu) * is) * m2);
                         if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (p < halo_pix) {
@@ -486,12 +496,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
                     // its backward needs no separate reduction pass over this tensor
                     const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
-                    f32x4 m;
-                    if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
-                    else m = rw * bsc + bsh;
                     f32x4 dz;
+                    if (a.bn_mask) {
+                        const int ch0 = n0 + qc * 4;
+                        const unsigned bits = a.bn_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                        for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
+                    } else {
+                        f32x4 m;
+                        if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
+                        else m = rw * bsc + bsh;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                    }
                     ssum += dz;
                     ssq += dz * ((rw - bmu) * bis);
                 } else {

@@ -120,7 +120,10 @@ class Engine:
         self.fuse_bn_reduce = True
         # ... and the BatchNorm-backward apply runs inside the stride-1 data gradients' input staging (IN_BNBWD)
         self.fuse_bn_apply = True
+        # the forward BN+residual+ReLU pass also emits 1-bit sign masks of the block outputs; the fused backward kernels read
+        # those instead of the activated tensors
         import os
+        self.use_sign_masks = os.environ.get("SPK_SIGN_MASKS", "1") == "1"
         self.fuse_apply_min_c = int(os.environ.get("SPK_FUSE_APPLY_MINC", "0"))   # experiment knob: skip the fusion below C channels
 
     # ---- helpers ---------------------------------------------------------------------------------------
@@ -246,10 +249,12 @@ class Engine:
         raw0, st = ops.stem_fwd(x, self.stem_conv.h.weight.data, stats=True)
         B, F, T, _ = raw0.shape
         t4 = self.stem_bn.finalize(st, B * F * T)
-        a = ops.bn_apply(raw0, t4[2], t4[3], relu=True)
+        use_masks = save and self.use_sign_masks
+        a = ops.bn_apply(raw0, t4[2], t4[3], relu=True, mask=use_masks)
+        a, amask = a if use_masks else (a, None)
         saved["raw0"] = raw0
         for b in self.blocks:
-            rec = {"x": a}
+            rec = {"x": a, "xmask": amask}
             raws = []
             h, aff = a, None
             for c, bn in zip(b.convs, b.bns):
@@ -260,12 +265,14 @@ class Engine:
             if b.ds is not None:
                 rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True)
                 td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2])
-                out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True)
+                out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True, mask=use_masks)
                 rec["rawd"] = rawd
             else:
-                out = ops.bn_apply(h, aff[0], aff[1], res=a, relu=True)
+                out = ops.bn_apply(h, aff[0], aff[1], res=a, relu=True, mask=use_masks)
+            out, amask = out if use_masks else (out, None)
             rec["raws"] = raws
             rec["out"] = out
+            rec["mask"] = amask
             if save:
                 saved["blocks"].append(rec)
             a = out
@@ -387,6 +394,8 @@ class Engine:
                 add_dz = True                                           # identity shortcut: dx = dgrad + dz
                 if c.stride == 1 and self.fuse_bn_reduce and prev is not None:
                     bnb = (prev[0], x, prev[1])                         # statistics for the previous block's last BN
+                    if rec.get("xmask") is not None:
+                        bnb = bnb + (rec["xmask"],)                     # sign bits of x instead of x itself
             if self.fuse_bn_apply and c.stride == 1 and c.cout >= self.fuse_apply_min_c:
                 if g_part is None:
                     g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
@@ -394,8 +403,11 @@ class Engine:
                                        bn.h.bias.grad, acc)
                 draw = torch.empty_like(raw)
                 dzb = torch.empty_like(raw) if last else None
+                inb = (raw, act, bn.t4, coef)
+                if last and rec.get("mask") is not None:
+                    inb = inb + (rec["mask"],)                          # sign bits of the block output instead of it
                 res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                     in_bnbwd=(raw, act, bn.t4, coef), side=(draw, dzb))
+                                     in_bnbwd=inb, side=(draw, dzb))
                 if last:
                     dz = dzb
             else:

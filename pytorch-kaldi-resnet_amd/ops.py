@@ -126,6 +126,12 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         assert epi_add.shape == out.shape
     if relu:
         flags |= EPI_RELU
+    # sign masks (uint32 words, 32 channels each, written by bn_apply(mask=True)) replace the activated tensors where given
+    in_mask = in_bnbwd[4] if (in_bnbwd is not None and len(in_bnbwd) > 4) else None
+    bn_mask = bn_bwd[3] if (bn_bwd is not None and len(bn_bwd) > 3) else None
+    for mk, ref in ((in_mask, x), (bn_mask, out)):
+        if mk is not None:
+            assert mk.dtype == torch.int32 and mk.numel() == ref.numel() // 32, "sign mask shape"
     if in_bnbwd is not None:
         flags |= IN_BNBWD
         assert in_affine is None and side is not None and side[0].shape == x.shape
@@ -143,10 +149,11 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None,
          ptr(epi_add),
-         ptr(in_bnbwd[0]) if in_bnbwd else None, ptr(in_bnbwd[1]) if in_bnbwd else None,
+         ptr(in_bnbwd[0]) if in_bnbwd else None, ptr(in_bnbwd[1]) if (in_bnbwd and in_mask is None) else None,
          ptr(in_bnbwd[2]) if in_bnbwd else None, ptr(in_bnbwd[3]) if in_bnbwd else None,
+         ptr(in_mask), ptr(bn_mask),
          ptr(side[0]) if side else None, ptr(side[1]) if side else None,
-         ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if bn_bwd else None,
+         ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if (bn_bwd and bn_mask is None) else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, stream(),
          label="conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
@@ -365,15 +372,18 @@ def bn_eval_coeffs(gamma, beta, rm, rv, out2):
     call("spk_bn_eval_coeffs", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(out2[0]), ptr(out2[1]), C, BN_EPS, stream())
 
 
-def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None):
+def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, mask=False):
+    """out = [relu](raw*scale + shift [+ res | + res*rscale + rshift]).  mask=True also returns the sign bits of `out`
+    ([N][C/32] int32 words): the backward pass reads those instead of the activated tensor."""
     C = raw.shape[-1]
     N = raw.numel() // C
     if out is None:
         out = torch.empty_like(raw)
+    mk = torch.empty(N * (C // 32), device=raw.device, dtype=torch.int32) if mask else None
     call("spk_bn_apply", ptr(raw), ptr(scale), ptr(shift), ptr(res),
-         ptr(res_affine[0]) if res_affine else None, ptr(res_affine[1]) if res_affine else None, ptr(out), N, C,
+         ptr(res_affine[0]) if res_affine else None, ptr(res_affine[1]) if res_affine else None, ptr(out), ptr(mk), N, C,
          1 if relu else 0, stream())
-    return out
+    return (out, mk) if mask else out
 
 
 def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,

@@ -41,6 +41,14 @@ def nchw(x):   # NHWC cuda -> NCHW cpu
     return x.cpu().permute(0, 3, 1, 2).contiguous()
 
 
+def sign_mask(act_nchw):
+    """[B,C,H,W] cpu tensor -> the int32 sign-mask words spk_bn_apply emits for it ([B*H*W][C/32], bit k = channel 32j+k > 0)."""
+    B, C, H, Wd = act_nchw.shape
+    bits = (act_nchw.permute(0, 2, 3, 1).reshape(-1, C // 32, 32) > 0).numpy().astype(np.uint64)
+    words = (bits << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+    return torch.from_numpy(words.view(np.int32).reshape(-1)).cuda()
+
+
 CONV_CASES = [
     # B, Cin, Cout, H, W, ksize, stride
     (2, 32, 32, 9, 13, 3, 1),
@@ -121,9 +129,11 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
         bn4 = torch.stack([rnd(11, Cin, scale=0.3), rnd(12, Cin, scale=0.2, shift=1.0), rnd(13, Cin, scale=0.5, shift=1.0),
                            rnd(14, Cin, scale=0.4)])
         actt = rnd(15, B, Cin, H, Wd)
-        for act in (None, actt):
-            dxb, part = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt),
-                                       bn_bwd=(nhwc(rawt), None if act is None else nhwc(act), bn4.cuda()))
+        for act, use_mask in ((None, False), (actt, False), (actt, True)):
+            bnb = (nhwc(rawt), None if act is None else nhwc(act), bn4.cuda())
+            if use_mask:
+                bnb = bnb + (sign_mask(act),)        # 1-bit form of the same mask: identical result
+            dxb, part = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt), bn_bwd=bnb)
             assert relerr(nchw(dxb), gx + addt) < 2e-5
             v = (gx + addt).double()
             mask = ((rawt * bn4[2].view(1, -1, 1, 1) + bn4[3].view(1, -1, 1, 1)) > 0) if act is None else (act > 0)
@@ -142,15 +152,17 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
                             rnd(25, Co, scale=0.4)])
         coef = torch.stack([rnd(26, Co, scale=0.3, shift=1.0), rnd(27, Co, scale=0.05), rnd(28, Co, scale=0.05)])
         v4 = lambda t: t.view(1, -1, 1, 1)
-        for act in (None, acto):
+        for act, use_mask in ((None, False), (acto, False), (acto, True)):
             mask = ((rawo * v4(bn4o[2]) + v4(bn4o[3])) > 0) if act is None else (act > 0)
             dzr = dy * mask
             xh = (rawo - v4(bn4o[0])) * v4(bn4o[1])
             draw_ref = v4(coef[0]) * (dzr - v4(coef[1]) - xh * v4(coef[2]))
             gx_ref, = torch.autograd.grad(F.conv2d(xr, wr, None, s, pad), [xr], grad_outputs=draw_ref)
             sd, sz = torch.zeros(B, ref.shape[2], ref.shape[3], Co, device="cuda"), torch.zeros(B, ref.shape[2], ref.shape[3], Co, device="cuda")
-            dxf = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt),
-                                 in_bnbwd=(nhwc(rawo), None if act is None else nhwc(act), bn4o.cuda(), coef.cuda()), side=(sd, sz))
+            inb = (nhwc(rawo), None if act is None else nhwc(act), bn4o.cuda(), coef.cuda())
+            if use_mask:
+                inb = inb + (sign_mask(act),)
+            dxf = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt), in_bnbwd=inb, side=(sd, sz))
             assert relerr(nchw(dxf), gx_ref + addt) < 3e-5, "dgrad IN_BNBWD"
             assert relerr(nchw(sd), draw_ref) < 1e-5, "side draw"
             assert relerr(nchw(sz), dzr) == 0.0, "side dz"
@@ -167,6 +179,20 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     ops.conv_wgrad(xg, nhwc(dy), dw, k, s, in_affine=(isc.cuda(), ish.cuda()), accumulate=True)
     e = relerr(dw.cpu(), 2 * gw2)
     assert e < 3e-5, "wgrad accumulate %g" % e
+
+
+def test_bn_apply_sign_mask(ops):
+    """spk_bn_apply's optional 1-bit output: bit k of word j of a pixel = (out[pixel][32 j + k] > 0)."""
+    torch.manual_seed(1)
+    for C, N in ((32, 999), (128, 77), (256, 1031)):
+        raw = torch.randn(N, 1, 1, C)
+        res = torch.randn(N, 1, 1, C)
+        sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+        out, mk = ops.bn_apply(raw.cuda(), sc.cuda(), sh.cuda(), res=res.cuda(), relu=True, mask=True)
+        ref = torch.relu(raw * sc + sh + res)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+        want = sign_mask(out.cpu().permute(0, 3, 1, 2))
+        assert torch.equal(mk, want)
 
 
 @pytest.mark.parametrize("C,rows", [(32, 97280), (256, 4100), (64, 1025), (96, 1500)])
