@@ -72,7 +72,8 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
                   const float* in_act, const float* in_bn4, const float* in_coef, const unsigned* in_mask /* sign bits of
                   in_act, [pixel][Cin/32] words: read instead of it */, const unsigned* bn_mask /* same for bn_act,
-                  [pixel][Cout/32] */, float* side_draw, float* side_dz,
+                  [pixel][Cout/32] */, const unsigned* add_mask /* EPI_ADD adds only where the bit is set */,
+                  float* side_draw, float* side_dz,
                   const float* bn_raw, const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,

@@ -41,6 +41,8 @@ struct ConvArgs {
     const float* in_coef;  //   [3][Cin]: gamma*invstd, mean(dz), mean(dz*xhat)  (spk_bn_bwd_finalize)
     const unsigned* in_mask;   //   alternative to in_act: its sign bits, [pixel][Cin/32] words (spk_bn_apply mask_out)
     const unsigned* bn_mask;   // SPK_EPI_BNBWD: alternative to bn_act, [pixel][Cout/32] words
+    const unsigned* add_mask;  // SPK_EPI_ADD: add only where the bit is set (epi_add = gradient wrt a ReLU output, bits = its
+                               //   sign mask: the shortcut gradient dz = dout*[out > 0] formed here instead of stored and re-read)
     float* side_draw;      //   optional side outputs of the tile's own pixels: the transformed value (gradient wrt the raw
     float* side_dz;        //   conv output, consumed by the weight gradient) and dz = in*mask (the shortcut gradient)
     const float* bn_raw;   // SPK_EPI_BNBWD: raw conv output of the BatchNorm whose backward statistics are reduced here
@@ -484,7 +486,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #endif
                 float* dst = a.out + ob + qc * 4;
                 if (flags & SPK_EPI_AFFINE) v = v * es + eh;
-                if (flags & SPK_EPI_ADD) v += *(const f32x4*)(a.epi_add + ob + qc * 4);
+                if (flags & SPK_EPI_ADD) {
+                    f32x4 ad = *(const f32x4*)(a.epi_add + ob + qc * 4);
+                    if (a.add_mask) {
+                        const int ch0 = n0 + qc * 4;
+                        const unsigned bits = a.add_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ad[c] = ((bits >> c) & 1u) ? ad[c] : 0.f;
+                    }
+                    v += ad;
+                }
                 if (flags & SPK_EPI_RELU) {
                     v[0] = fmaxf(v[0], 0.f);
                     v[1] = fmaxf(v[1], 0.f);

@@ -38,7 +38,8 @@ static int launch_conv(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale,
                              const float* in_shift, const float* epi_scale, const float* epi_shift,
                              const float* epi_add, const float* in_raw, const float* in_act, const float* in_bn4,
-                             const float* in_coef, const unsigned* in_mask, const unsigned* bn_mask, float* side_draw, float* side_dz,
+                             const float* in_coef, const unsigned* in_mask, const unsigned* bn_mask, const unsigned* add_mask, float* side_draw,
+                             float* side_dz,
                              const float* bn_raw,
                              const float* bn_act, const float* bn4, float* stats, int B, int IH, int IW, int Cin, int OH,
                              int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
@@ -73,7 +74,8 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;
     a.bn_raw = bn_raw; a.bn_act = bn_act; a.bn4 = bn4;
     a.in_raw = in_raw; a.in_act = in_act; a.in_bn4 = in_bn4; a.in_coef = in_coef; a.side_draw = side_draw; a.side_dz = side_dz;
-    a.in_mask = in_mask; a.bn_mask = bn_mask;
+    a.in_mask = in_mask; a.bn_mask = bn_mask; a.add_mask = add_mask;
+    SPK_REQUIRE(!add_mask || ((flags & SPK_EPI_ADD) && Cout % 32 == 0), "spk_conv_mfma: add_mask needs EPI_ADD and Cout %% 32 == 0");
     SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);
     a.B = B; a.IHp = IH; a.IWp = IW; a.ips = ips; a.IH = (IH + ips - 1) / ips; a.IW = (IW + ips - 1) / ips; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
     a.IS = IS; a.OS = OS; a.ooy = ooy; a.oox = oox; a.TH = TH; a.TW = TW;

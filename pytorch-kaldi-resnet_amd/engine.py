@@ -402,12 +402,19 @@ class Engine:
                 coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,
                                        bn.h.bias.grad, acc)
                 draw = torch.empty_like(raw)
-                dzb = torch.empty_like(raw) if last else None
+                # the shortcut gradient dz = dout*[out > 0]: with an identity shortcut and sign masks it is never stored - the
+                # first conv's data-gradient epilogue re-forms it from dout and the mask bits
+                lazy_dz = b.ds is None and rec.get("mask") is not None and n > 1
+                dzb = torch.empty_like(raw) if (last and not lazy_dz) else None
                 inb = (raw, act, bn.t4, coef)
                 if last and rec.get("mask") is not None:
                     inb = inb + (rec["mask"],)                          # sign bits of the block output instead of it
-                res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                     in_bnbwd=inb, side=(draw, dzb))
+                if add_dz and lazy_dz:
+                    res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
+                                         in_bnbwd=inb, side=(draw, dzb))
+                else:
+                    res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
+                                         in_bnbwd=inb, side=(draw, dzb))
                 if last:
                     dz = dzb
             else:

@@ -23,7 +23,7 @@ _SIGS = {
     "spk_pack_conv_weight_split": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_pack_job_bytes": [],
     "spk_pack_conv_weights_batched": [_P, _I, _I, _P],
-    "spk_conv_mfma": [_P] * 20 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P],
+    "spk_conv_mfma": [_P] * 21 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 16 + [_P],
     "spk_conv_wgrad_limits": [_I, _IP, _IP],
     "spk_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -95,7 +95,7 @@ class PackTable:
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
-                 bn_bwd=None, in_bnbwd=None, side=None, split=0):
+                 bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -129,7 +129,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     # sign masks (uint32 words, 32 channels each, written by bn_apply(mask=True)) replace the activated tensors where given
     in_mask = in_bnbwd[4] if (in_bnbwd is not None and len(in_bnbwd) > 4) else None
     bn_mask = bn_bwd[3] if (bn_bwd is not None and len(bn_bwd) > 3) else None
-    for mk, ref in ((in_mask, x), (bn_mask, out)):
+    for mk, ref in ((in_mask, x), (bn_mask, out), (add_mask, out)):
         if mk is not None:
             assert mk.dtype == torch.int32 and mk.numel() == ref.numel() // 32, "sign mask shape"
     if in_bnbwd is not None:
@@ -151,7 +151,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(epi_add),
          ptr(in_bnbwd[0]) if in_bnbwd else None, ptr(in_bnbwd[1]) if (in_bnbwd and in_mask is None) else None,
          ptr(in_bnbwd[2]) if in_bnbwd else None, ptr(in_bnbwd[3]) if in_bnbwd else None,
-         ptr(in_mask), ptr(bn_mask),
+         ptr(in_mask), ptr(bn_mask), ptr(add_mask),
          ptr(side[0]) if side else None, ptr(side[1]) if side else None,
          ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if (bn_bwd and bn_mask is None) else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
@@ -227,9 +227,10 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
 
 
 def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None, in_bnbwd=None,
-               side=None):
+               side=None, add_mask=None):
     """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
-    `add` (same shape as dx) is summed in the epilogue; accumulate=True adds onto the existing `out`.
+    `add` (same shape as dx) is summed in the epilogue (only where the bits of `add_mask`, sign-mask words of the same
+    shape, are set when that is given); accumulate=True adds onto the existing `out`.
     bn_bwd = (raw, act or None, bn4[4][Cin]) (stride-1 only): dx is the gradient wrt the output of that BatchNorm
     (+ReLU); the launch also returns the BatchNorm-backward partial sums -> (dx, partial).
     in_bnbwd = (raw, act or None, bn4[4][Cout], coef[3][Cout]) + side = (draw_out, dz_out or None) (stride-1 only): `dy` is
@@ -249,9 +250,9 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
         else:
             taps = [(0, 0, 0)]
         st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd, in_bnbwd,
-                          side, split=split_for(ksize))
+                          side, split=split_for(ksize), add_mask=add_mask)
         return (out, st) if bn_bwd is not None else out
-    assert stride == 2 and bn_bwd is None and in_bnbwd is None
+    assert stride == 2 and bn_bwd is None and in_bnbwd is None and add_mask is None
     if ksize == 1:
         # only even input pixels receive gradient from a strided 1x1 conv
         if not accumulate:

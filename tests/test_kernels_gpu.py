@@ -118,6 +118,11 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     dx2 = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt))
     e = relerr(nchw(dx2), gx + addt)
     assert e < 2e-5, "dgrad+add %g" % e
+    if s == 1:
+        gate = rnd(16, B, Cin, H, Wd)
+        dx2m = ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), add=nhwc(addt), add_mask=sign_mask(gate))
+        e = relerr(nchw(dx2m), gx + addt * (gate > 0))
+        assert e < 2e-5, "dgrad + masked add %g" % e
     dx3 = nhwc(addt).clone()
     ops.conv_dgrad(nhwc(dy), wpk_t, Cin, k, s, (H, Wd), out=dx3, accumulate=True)
     e = relerr(nchw(dx3), gx + addt)
