@@ -301,7 +301,7 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     if tiling.AUTOTUNE and wkey not in tiling.FORCE_WGRAD and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         tiling.FORCE_WGRAD[wkey] = tiling._wgrad_tile(*wkey)      # placeholder: stops the recursion below
         _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
-    TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride)
+    TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split_for(ksize))
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)

@@ -24,6 +24,7 @@ WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
 FORCE_CONV = {}
 FORCE_CONV_SPLIT = {}     # the same launch shapes in the bf16-split operand mode (112 B of LDS per pixel, faster MFMA phase)
 FORCE_WGRAD = {}
+FORCE_WGRAD_SPLIT = {}    # weight-gradient tiles of the bf16-split kernel (K = 16 pixels per MFMA: tiles of 16 k pixels pad least)
 
 
 def _load_table():
@@ -38,6 +39,8 @@ def _load_table():
             FORCE_CONV_SPLIT[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("wgrad", {}).items():
             FORCE_WGRAD[tuple(int(x) for x in k.split(","))] = tuple(v)
+        for k, v in t.get("wgrad_split", {}).items():
+            FORCE_WGRAD_SPLIT[tuple(int(x) for x in k.split(","))] = tuple(v)
 
 
 # Autotune on first use (the analogue of the reference's `cudnn.benchmark = True`, scripts/train_resnet.py:231):
@@ -102,8 +105,10 @@ def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     return _conv_tile(*key)
 
 
-def wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
+def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=0):
     key = (OH, OW, Cin, Cout, ksize, stride)
+    if split and key in FORCE_WGRAD_SPLIT:
+        return FORCE_WGRAD_SPLIT[key]
     if key in FORCE_WGRAD:
         return FORCE_WGRAD[key]
     return _wgrad_tile(*key)

@@ -257,6 +257,13 @@ def test_tile_lookup_by_mode_and_operand_mode(monkeypatch):
         assert TH * TW <= 128 * MT and shape[6] % (32 * NT) == 0
         halo = ((TH - 1) * shape[2] + shape[3]) * ((TW - 1) * shape[2] + shape[4])
         assert halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD
+    # weight-gradient tiles: the split kernel has its own measured table (tiles of 64 pixels = four 16-pixel MFMA steps)
+    wkey = (20, 75, 128, 128, 3, 1)
+    assert tiling.wgrad_tile(*wkey) == tiling.FORCE_WGRAD[wkey]
+    assert tiling.wgrad_tile(*wkey, split=6) == tiling.FORCE_WGRAD_SPLIT.get(wkey, tiling.FORCE_WGRAD[wkey])
+    for key, (TH, TW, WN) in list(tiling.FORCE_WGRAD.items()) + list(tiling.FORCE_WGRAD_SPLIT.items()):
+        k, st = key[4], key[5]
+        assert TH * TW <= tiling.WGRAD_MAX_TILE[WN] and ((TH - 1) * st + k) * ((TW - 1) * st + k) <= tiling.WGRAD_MAX_HALO and TW % 2 == 0
     for c in tiling.conv_candidates(20, 75, 1, 3, 3, 9, 128, split=6):
         assert (c[2], c[3]) in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2), (1, 4))
 

@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--sweep-bnbwd", action="store_true", help="sweep tiles of the stride-1 data gradients in fused BatchNorm-backward mode and merge them into the table")
 ap.add_argument("--no-wgrad", action="store_true", help="with --sweep: leave the weight-gradient table alone")
+ap.add_argument("--wgrad-only", action="store_true", help="with --sweep: sweep only the weight-gradient tiles (section wgrad, or wgrad_split in a split operand mode)")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--feat", type=int, default=80)
@@ -68,7 +69,7 @@ def conv_candidates(OH, OW, IS, ks, Cout):
 SECTION = "conv_split" if ops.SPLIT else "conv"
 FORCE = tiling.FORCE_CONV_SPLIT if ops.SPLIT else tiling.FORCE_CONV
 table = json.load(open(args.out)) if os.path.exists(args.out) else {}
-for sec in ("conv", "conv_split", "wgrad"):
+for sec in ("conv", "conv_split", "wgrad", "wgrad_split"):
     table.setdefault(sec, {})
 rows = []
 if args.sweep_bnbwd:
@@ -115,7 +116,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
     dx = torch.empty(B, H, W, Cin, device=dev)
     flops = 2.0 * B * OH * OW * Cout * Cin * k * k
     key = (OH, OW, s if k == 3 else 1, k, k, k * k, Cout)      # strided 1x1 launches run as IS = 1 over a strided view
-    if args.sweep and (k == 3 or not ops.SPLIT):
+    if args.sweep and not args.wgrad_only and (k == 3 or not ops.SPLIT):
         res = []
         tab = FORCE if k == 3 else tiling.FORCE_CONV
         for cand in conv_candidates(OH, OW, s if k == 3 else 1, k, Cout):
@@ -146,7 +147,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
                     ty, tx = -(-OH // TH), -(-OW // TW)
                     cands.append((ty * tx * (TH * TW + 24.0), TH, TW))
             cands.sort()
-            for _, TH, TW in cands[:8]:
+            for _, TH, TW in cands[:16]:
                 tiling.FORCE_WGRAD[wkey] = (TH, TW, WN)
                 try:
                     ms = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
@@ -155,7 +156,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
                 res.append((ms, (TH, TW, WN)))
         res.sort()
         tiling.FORCE_WGRAD[wkey] = res[0][1]
-        table["wgrad"][",".join(map(str, wkey))] = list(res[0][1])
+        table["wgrad_split" if (ops.SPLIT and k == 3) else "wgrad"][",".join(map(str, wkey))] = list(res[0][1])
         print("%-12s wgrad best %s %.3f ms %.1f TF | top: %s" % (name, res[0][1], res[0][0], flops / res[0][0] / 1e9,
               " ".join("%s:%.3f" % (c, m) for m, c in res[:5])), flush=True)
     t_fwd = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
