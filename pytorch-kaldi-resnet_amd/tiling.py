@@ -111,7 +111,7 @@ def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=0):
         return FORCE_WGRAD_SPLIT[key]
     if key in FORCE_WGRAD:
         return FORCE_WGRAD[key]
-    return _wgrad_tile(*key)
+    return _wgrad_tile(*key, split=1 if split else 0)
 
 
 @lru_cache(maxsize=None)
@@ -150,8 +150,9 @@ def _conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
 
 
 @lru_cache(maxsize=None)
-def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
-    """-> (TH, TW, WN).  TW even; halo <= WGRAD_MAX_HALO pixels, tile <= WGRAD_MAX_TILE[WN] pixels."""
+def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=0):
+    """-> (TH, TW, WN).  TW even; halo <= WGRAD_MAX_HALO pixels, tile <= WGRAD_MAX_TILE[WN] pixels.  The split kernel
+    consumes 16 pixels per MFMA step: its cost counts the tile padded to a multiple of 16."""
     WN = 1 if Cout == 32 else 2
     best = None
     OWe = OW + (OW & 1)
@@ -164,7 +165,8 @@ def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride):
                 continue
             ty, tx = -(-OH // TH), -(-OW // TW)
             # MFMA work ~ padded pixels; every region also pays two barriers and a pipeline fill (~24 pixel-equivalents)
-            cost = ty * tx * (TH * TW + 24.0 + 0.1 * halo)
+            pix = -(-(TH * TW) // 16) * 16 if split else TH * TW
+            cost = ty * tx * (pix + 24.0 + 0.1 * halo)
             key = (cost, -TH * TW)
             if best is None or key < best[0]:
                 best = (key, (TH, TW, WN))
