@@ -12,7 +12,15 @@ Prints ONE JSON line (see the repo contract) with two extra objects:
                  algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch
                  stream, against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)
   cpu_baseline - the CPU oracle (oracle/spk_oracle.py, a torch-CPU port of the reference path) timed on this
-                 host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
+                 host's cores on a bounded sample of the same workload (rank 0, N = 1 only): 2 warm-ups + median of 5
+                 steps of the C2-micro (bs 32, T = 300) and the C1 shape (bs 32, T = 200), train step and predict
+  eer          - cosine-score EER of HIP embeddings of a seeded 2048-utterance synthetic set, and of the CPU oracle's
+                 embeddings of a 256-utterance subset next to the HIP EER on the same trials (reference test.sh:33-39,65-74)
+
+  --config c1|c2|c4|c5 selects a BASELINE.json configuration by name (c2 = the headline, default):
+     c1  ResNet-34 + AAM, 10 speakers, bs 32, 200 frames       (the run_aam_cpu.sh shape, on the GPU)
+     c4  ResNet-101 + AAM, 5994 speakers, one chunk length per step in [200, 400], bs 256 (per-length hipGraph cache)
+     c5  eval-mode embedding extraction (predict), bs 512, 300 frames
 """
 import argparse
 import json
@@ -67,12 +75,26 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    return ap.parse_args()
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU steps per leg (median reported) after 2 warm-ups")
+    ap.add_argument("--no-eer", action="store_true")
+    ap.add_argument("--config", choices=["c1", "c2", "c4", "c5"], default=None,
+                    help="BASELINE.json configuration preset (c2 = headline = the defaults)")
+    a = ap.parse_args()
+    if a.config == "c1":
+        a.batch, a.frames, a.speakers = 32, 200, 10
+    elif a.config == "c4":
+        a.arch, a.speakers, a.frames_range = "resnet101", 5994, [200, 400]
+    elif a.config == "c5":
+        a.mode, a.batch = "predict", 512
+    return a
 
 
 def cpu_baseline(args):
-    """Oracle train step (fwd + CE + autograd bwd + SGD) on the host cores; bounded sample."""
+    """The CPU oracle on the host cores, bounded sample (SURVEY.md section 8d / BASELINE.md section 3): per leg 2 warm-ups, then
+    the median of --cpu-steps steps.  Legs: C2-micro (bs 32 x 300 frames, S = 1211) train step + predict - the same
+    workload as the metric, `value` - and the C1 shape (bs 32 x 200 frames, S = 10) train step + predict."""
+    import statistics
+
     from oracle import spk_oracle as O
     from oracle import weights as W
     try:
@@ -81,20 +103,112 @@ def cpu_baseline(args):
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(ncpu, 16)))   # the GPU box's CPU share is 16 cores per GPU
     bs = args.cpu_batch
-    st = O.to_torch_state(W.make_state(0, SPK, FEAT, "mean+std", "AAM", "resnet34"))
-    x, y = W.make_input(1234, bs, FEAT, args.frames, SPK)
-    x, y = torch.from_numpy(x), torch.from_numpy(y)
-    bufs = {}
-    O.train_step(st, bufs, x, y, 1e-4, weight_decay=5e-4)   # warm-up
-    log("cpu warm-up step done (%d threads)" % torch.get_num_threads())
-    t0 = time.time()
-    for i in range(args.cpu_steps):
-        O.train_step(st, bufs, x, y, 1e-4, weight_decay=5e-4)
-        log("cpu step %d done" % i)
-    dt = (time.time() - t0) / args.cpu_steps
-    return {"value": round(bs / dt, 3), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d train steps of bs%d x %d frames x %d mel, ResNet-34+AAM S=%d, torch %s CPU oracle "
-                      "(%.2f s/step)" % (args.cpu_steps, bs, args.frames, FEAT, SPK, torch.__version__, dt)}
+
+    def leg(frames, spk, what):
+        st = O.to_torch_state(W.make_state(0, spk, FEAT, "mean+std", "AAM", "resnet34"))
+        x, y = W.make_input(1234, bs, FEAT, frames, spk)
+        x, y = torch.from_numpy(x), torch.from_numpy(y)
+        bufs = {}
+
+        def one():
+            t = time.perf_counter()
+            if what == "train":
+                O.train_step(st, bufs, x, y, 1e-4, weight_decay=5e-4)
+            else:
+                with torch.no_grad():
+                    O.embed(st, x, "mean+std", "resnet34", train=False)
+            return time.perf_counter() - t
+        for _ in range(2):
+            one()
+        ts = [one() for _ in range(args.cpu_steps)]
+        med = statistics.median(ts)
+        log("cpu %s bs%d x %d frames: median %.3f s/step over %d steps" % (what, bs, frames, med, len(ts)))
+        return {"utt_per_s": round(bs / med, 3), "s_per_step_median": round(med, 4), "steps": len(ts), "warmup": 2}
+
+    c2t = leg(args.frames, SPK, "train")
+    c2p = leg(args.frames, SPK, "predict")
+    c1t = leg(200, 10, "train")
+    c1p = leg(200, 10, "predict")
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": c2t["utt_per_s"], "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of %d train steps (after 2 warm-ups) of bs%d x %d frames x %d mel, ResNet-34+AAM S=%d, torch %s "
+                      "CPU oracle (%.2f s/step)" % (args.cpu_steps, bs, args.frames, FEAT, SPK, torch.__version__,
+                                                   c2t["s_per_step_median"]),
+            "host_cpu": cpu_model, "torch_threads": torch.get_num_threads(),
+            "c2_micro_train": c2t, "c2_micro_predict": c2p, "c1_train_bs32_t200": c1t, "c1_predict_bs32_t200": c1p}
+
+
+def eer_leg(dev):
+    """Cosine-score EER next to the CPU path's (north_star; reference test.sh:33-39,65-74: compute_mean -> cosine_score
+    --mean -> compute_eer).  Seeded synthetic set: 64 speakers x 32 utterances x 200 frames x 80 mel, N(0,1) plus a
+    per-speaker mean offset 0.5*N(0,1)[80], hashed weights, eval mode.  HIP extracts all 2048
+    utterances (20 000 seeded trials, scored on the device); the CPU oracle - the checker - extracts the first 256
+    (8 speakers; 4 000 seeded trials among them) and the HIP embeddings are scored on the same 4 000 trials."""
+    import contextlib
+
+    import numpy as np
+    from oracle import spk_oracle as O
+    from oracle import weights as W
+    from pytorch_kaldi_resnet_amd import scoring
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    nspk, per, T, sub = 64, 32, 200, 256
+    rs = np.random.RandomState(1234)
+    spk_mean = 0.5 * rs.randn(nspk, FEAT, 1).astype(np.float32)
+    lab = np.repeat(np.arange(nspk), per)
+    x = rs.randn(nspk * per, FEAT, T).astype(np.float32) + spk_mean[lab]
+    npst = W.make_state(11, 10, FEAT, "mean+std", "AAM", "resnet34")
+    with contextlib.redirect_stdout(sys.stderr):
+        m = NeuralSpeakerModel(10, FEAT, "mean+std", "AAM", 0.2, 30)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in npst.items()})
+    m = m.to(dev).eval()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        emb = torch.cat([m.predict(torch.from_numpy(x[i:i + 512]).to(dev)) for i in range(0, len(x), 512)]).cpu().numpy()
+    t_hip = time.perf_counter() - t0
+    st = O.to_torch_state(npst)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = torch.cat([O.embed(st, torch.from_numpy(x[i:i + 32]), "mean+std", "resnet34", train=False)
+                         for i in range(0, sub, 32)]).numpy()
+    t_cpu = time.perf_counter() - t0
+    names = ["u%04d" % i for i in range(len(x))]
+
+    def eer_of(vecs, n, ntrials, seed, backend):
+        import tempfile
+        r = np.random.RandomState(seed)
+        a, b = r.randint(0, n, ntrials), r.randint(0, n, ntrials)
+        keep = a != b
+        a, b = a[keep], b[keep]
+        table = {names[i]: vecs[i] for i in range(n)}
+        mean = np.mean(np.stack([vecs[i] for i in range(n)]).astype(np.float32), axis=0)
+        with tempfile.NamedTemporaryFile("w", suffix=".trials", delete=False) as f:
+            for i, j in zip(a, b):
+                f.write("%s %s %s\n" % (names[i], names[j], "target" if lab[i] == lab[j] else "nontarget"))
+            path = f.name
+        try:
+            sc, lb = scoring.cosine_score(table, table, path, mean, backend=backend)
+        finally:
+            os.unlink(path)
+        return scoring.compute_eer(sc, lb), int(lb.sum()), len(lb)
+
+    e_all, tgt_all, n_all = eer_of(emb, len(x), 20000, 77, "hip")
+    e_hs, tgt_s, n_s = eer_of(emb[:sub], sub, 4000, 78, "hip")
+    e_cs, _, _ = eer_of(ref, sub, 4000, 78, "host")
+    e64, r64 = emb[:sub].astype(np.float64), ref.astype(np.float64)
+    cos = (e64 * r64).sum(1) / (np.linalg.norm(e64, axis=1) * np.linalg.norm(r64, axis=1))
+    return {"hip_2048_utts": round(e_all, 5), "trials_2048": n_all, "targets_2048": tgt_all,
+            "hip_subset": round(e_hs, 5), "cpu_oracle_subset": round(e_cs, 5), "subset_utts": sub, "trials_subset": n_s,
+            "targets_subset": tgt_s, "max_1_minus_cos_subset": float((1.0 - cos).max()),
+            "hip_extract_s": round(t_hip, 3), "cpu_oracle_extract_s": round(t_cpu, 3),
+            "data": "64 speakers x 32 utts x 200 frames x 80 mel, N(0,1) + 0.5*N(0,1) per-speaker offset, seed 1234; hashed "
+                    "weights (random init: EER reflects the input offsets, not a trained model)"}
 
 
 def embedding_parity(dev):
@@ -186,7 +300,6 @@ def main():
         lens = [rng.randint(lo, hi) for _ in range(8)]      # 8 distinct lengths, cycled: --warmup 8 touches each once
         sched = [lens[i % 8] for i in range(args.warmup + args.steps)]
         var_x = {t: torch.randn(args.batch, FEAT, t, device=dev, generator=gen) for t in sorted(set(sched))}
-        args.no_graph = True
     step_no = [0]
     eng = model.engine()
     if os.environ.get("SPK_SIDE_STREAM", "1") == "0":
@@ -200,18 +313,23 @@ def main():
     else:
         step = None
 
-    # Default launch mode: the whole forward + CE + backward replayed as ONE hipGraph (host-load independent); with
-    # N > 1 the flat 27.8 MB gradient arena is then all-reduced in one RCCL call (~0.5 ms of a ~110 ms step) before
-    # SGD.  --no-graph launches eagerly and overlaps stage-bucketed all-reduces with the backward kernels instead.
+    # Default launch mode: weight re-pack + forward + CE + backward replayed as hipGraphs (host-load independent).  N = 1: one
+    # graph.  N > 1: six graph segments cut where backward finishes a ResNet stage; between two replays the host enqueues
+    # that stage's RCCL all-reduce on the communication stream, so the collective overlaps the remaining backward kernels
+    # (engine.GraphedTrainStep(segmented=True)).  --no-graph launches every kernel eagerly with the same overlap.
     graphed = None
+    graphs = {}          # chunk length -> GraphedTrainStep (variable-length mode: one graph per distinct length, one shared pool)
     if args.mode == "train" and not args.no_graph:
         from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
-        try:
-            graphed = GraphedTrainStep(eng, args.batch, args.frames)   # fwd + CE + bwd as one hipGraph
-        except Exception as e:     # keep the benchmark alive: same kernels, launched eagerly
-            log("hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e))
-            graphed = None
-            torch.cuda.synchronize()
+        # a capture failure is a real fault (HIP error, shape bug): surface it instead of silently timing another path
+        if var_x is None:
+            graphed = graphs[args.frames] = GraphedTrainStep(eng, args.batch, args.frames, segmented=world > 1)
+        else:
+            for t in sorted(var_x, reverse=True):           # longest first: it sizes the shared pool
+                graphs[t] = GraphedTrainStep(eng, args.batch, t, segmented=world > 1,
+                                             pool=graphed.pool() if graphed is not None else None)
+                graphed = graphed or graphs[t]
+                log("captured the step for %d frames" % t)
 
     def cur_x():
         if var_x is None:
@@ -221,13 +339,14 @@ def main():
         return var_x[t]
 
     def train_step():
+        xb = cur_x()
         if graphed is not None and PROFILE_OFF():
-            loss, _, _ = graphed(x, y)
-            red.allreduce_all()
+            loss, _, _ = graphs[xb.shape[2]](xb, y, red.on_stage_done if world > 1 else None)
+            red.finish()
             opt.step()
             return loss
         opt.zero_grad(set_to_none=True)
-        loss, _, _ = eng.loss_and_grad(cur_x(), y, red.on_stage_done if world > 1 else None)
+        loss, _, _ = eng.loss_and_grad(xb, y, red.on_stage_done if world > 1 else None)
         red.finish()
         opt.step()
         return loss
@@ -238,9 +357,12 @@ def main():
     if step is None:
         step = train_step
     log("model built, starting warm-up")
+    first_loss = None
     for i in range(args.warmup):
-        step()
+        l0 = step()
         torch.cuda.synchronize()
+        if first_loss is None:
+            first_loss = float(l0)
         log("warm-up step %d done" % i)
     torch.cuda.synchronize()
     if world > 1:
@@ -260,6 +382,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     lossv = float(loss)
+    if first_loss is None:
+        first_loss = lossv
+    repack_ok = None
+    if graphed is not None and args.mode == "train":
+        # Proof that every replay trains on the weights the optimizer just wrote (scripts/train_resnet.py:316-328): the last
+        # opt.step() changed the parameter arena; one more replay must leave the packed operands of the convolutions equal to
+        # a fresh pack of the CURRENT weights.  A graph that does not contain the re-pack fails here.
+        g0 = graphs[sorted(graphs)[0]]
+        g0(var_x[sorted(graphs)[0]] if var_x is not None else x, y)
+        bad = []
+        for cv in list(eng._all_convs())[::7]:
+            for transpose, buf in ((False, cv.wpk), (True, cv.wpk_t)):
+                if not torch.equal(ops.pack_conv_weight(cv.h.weight.data, transpose), buf):
+                    bad.append((cv.cin, cv.cout, cv.k, transpose))
+        torch.cuda.synchronize()
+        repack_ok = not bad
+        if bad:
+            raise SystemExit("bench: the replayed hipGraph uses stale packed conv weights %s - not a valid training step" % bad)
     log("timed region done: %.3f s for %d steps (host enqueue %.1f ms/step)" % (dt, args.steps, t_host / args.steps * 1e3))
 
     roofline = None
@@ -294,18 +434,28 @@ def main():
             a[2] += 1
         name, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fsum / tsum / 1e12
-        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process)
-        traffic = None
+        # HBM traffic of that kernel: rocprofv3 cannot run inside this process, so this is the COMMITTED PMC pass of the
+        # same command (profiles/pmc_traffic.json) - used only while the device sources still hash to what it measured
+        traffic, traffic_note = None, "no committed PMC pass for this kernel"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            ent = json.load(open(pmc))["kernels"].get(name.replace(",", ", "))
-            if ent:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("spk_build", os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "build.py"))
+            bmod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bmod)
+            pj = json.load(open(pmc))
+            ent = pj["kernels"].get(name.replace(",", ", "))
+            if pj.get("csrc_fingerprint") != bmod.csrc_fingerprint():
+                traffic_note = "committed PMC pass is stale (csrc changed since %s): refused" % pj.get("csrc_fingerprint")
+            elif ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
+                traffic_note = ("committed PMC pass @ csrc %s: HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                "rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json)" % pj["csrc_fingerprint"])
         peak, peak_note = mfma_peak(name)
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "peak_note": peak_note,
                     "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                    "traffic_note": traffic_note,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
                     "event_bracket_overhead_us": round(overhead_ms * 1e3, 1),
                     "gflop_per_launch": round(fsum / n / 1e9, 3),
@@ -345,6 +495,11 @@ def main():
         log("cpu baseline done")
         parity = embedding_parity(dev)
         log("embedding parity vs oracle: max 1-cos = %.3e" % parity)
+    eer = None
+    if rank == 0 and world == 1 and not args.no_eer and not args.no_cpu_baseline and headline:
+        eer = eer_leg(dev)
+        log("EER leg done: hip %.4f (2048 utts), subset hip %.4f vs cpu oracle %.4f" % (
+            eer["hip_2048_utts"], eer["hip_subset"], eer["cpu_oracle_subset"]))
     if rank == 0:
         gb = args.batch * world
         arch_name = {"resnet34": "ResNet-34", "resnet101": "ResNet-101"}[args.arch]
@@ -363,9 +518,14 @@ def main():
                                       frames_desc, FEAT, args.batch),
                        "global_batch": gb, "frames": args.frames if var_x is None else list(args.frames_range),
                        "feat_dim": FEAT, "speakers": nspk,
-                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed is not None else "eager",
+                       "parallelism": "dp%d" % world,
+                       "launch": ("eager" if graphed is None else "hipGraph replay (%d graph%s%s)" % (
+                           len(graphs) * len(graphed.segments), "s" if len(graphs) * len(graphed.segments) > 1 else "",
+                           ", stage-segmented with the all-reduce between segments" if world > 1 else "")),
                        "mfma": mfma_mode},
-            "final_loss": round(lossv, 4),
+            "first_loss": round(first_loss, 4), "final_loss": round(lossv, 4),
+            "loss_decreased_on_the_fixed_batch": bool(lossv < first_loss) if args.mode == "train" else None,
+            "graph_replay_repacks_weights": repack_ok, "eer": eer,
             "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native,
             "embedding_cosine_delta_vs_oracle": parity,
         }

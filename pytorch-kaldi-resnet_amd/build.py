@@ -10,6 +10,16 @@ SOURCES = ["err.cpp", "conv_mfma.hip", "conv_wgrad.hip", "stem.hip", "bn.hip", "
            "sgd.hip", "score.hip", "conv_split.hip", "conv_wgrad_split.hip", "pack.hip"]
 
 
+def csrc_fingerprint():
+    """sha256 over the device sources: ties a committed profile (profiles/pmc_traffic.json) to the kernels it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -452,13 +452,27 @@ class Engine:
         return loss, logits, rank
 
 
-class GraphedTrainStep:
-    """forward + CE + backward of one fixed-shape batch captured into a hipGraph (torch.cuda.CUDAGraph): one host
-    launch per step instead of ~450, so a busy host cannot starve the GPU.  Inputs are copied into static buffers;
-    gradients land in the model's flat gradient arena exactly as in the eager path (always overwritten).
-    The optimizer step stays outside the graph (its learning rate changes per epoch)."""
+STAGE_ORDER = ["head", "layer4", "layer3", "layer2", "layer1", "stem"]     # the order backward finishes the stages in
 
-    def __init__(self, engine, batch, frames, warmup=2, side_stream=None):
+
+class GraphedTrainStep:
+    """weight re-pack + forward + CE + backward of one fixed-shape batch captured as hipGraphs (torch.cuda.CUDAGraph): one
+    host launch per step instead of ~450, so a busy host cannot starve the GPU.  Inputs are copied into static buffers;
+    gradients land in the model's flat gradient arena exactly as in the eager path (always overwritten).
+    The optimizer step stays outside the graph (its learning rate changes per epoch).
+
+    segmented=False (one GPU): ONE graph.
+    segmented=True (data parallel): the step is cut where backward finishes a ResNet stage - six graphs sharing one
+    memory pool, replayed back to back.  Between two replays the host enqueues that stage's gradient all-reduce on the
+    communication stream (`on_stage_done(name)`, parallel.GradAllReducer), so the RCCL kernels of stage k overlap the
+    data / weight gradients of stages k-1..stem exactly as in the eager path (reference: DDP's bucketed all-reduce
+    overlapped with backward, scripts/train_resnet.py:183-185,327), with 6 host launches per step instead of ~450 and
+    no collective inside a captured region."""
+
+    def __init__(self, engine, batch, frames, warmup=2, side_stream=None, segmented=False, pool=None):
+        """pool: memory pool of another GraphedTrainStep of the same engine (`other.pool()`): steps for different chunk
+        lengths are never replayed concurrently, so they can share one pool - the cache of per-length graphs then costs
+        the activation memory of the longest length, not the sum."""
         import os
         if side_stream is None:
             side_stream = os.environ.get("SPK_GRAPH_SIDE", "0") == "1"
@@ -487,18 +501,62 @@ class GraphedTrainStep:
             b.copy_(sb)
         for p in m.parameters():
             p.grad = None                      # captured backward overwrites (no accumulation)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: helper threads of other libraries (the RCCL watchdog) may touch the device during capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss, self.logits, self.rank = engine.loss_and_grad(self.x, self.y)
+        # The optimizer rewrites the weights between replays (scripts/train_resnet.py:316-328: forward runs on what
+        # optimizer.step() just wrote), so the weight re-pack MUST be a node of the graph: the warm-up steps left the
+        # engine clean, mark it dirty so that the capture records the batched pack launch (its device-resident job table
+        # was built during warm-up and is kept alive by self.pack_table).
+        engine.dirty = True
+        self.segments = []                     # [(graph, stage name reported after it or None)]
+        cap = {"g": None, "ctx": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            kw = {"pool": self.segments[0][0].pool()} if self.segments else ({"pool": pool} if pool is not None else {})
+            # thread_local: helper threads of other libraries (the RCCL watchdog) may touch the device during capture
+            ctx = torch.cuda.graph(g, capture_error_mode="thread_local", **kw)
+            ctx.__enter__()
+            cap["g"], cap["ctx"] = g, ctx
+
+        def end(name):
+            cap["ctx"].__exit__(None, None, None)
+            self.segments.append((cap["g"], name))
+            cap["g"] = cap["ctx"] = None
+
+        def cut(name):                         # Engine.backward reports: every gradient of stage `name` is enqueued
+            end(name)
+            if name != STAGE_ORDER[-1]:
+                begin()
+
+        begin()
+        try:
+            self.loss, self.logits, self.rank = engine.loss_and_grad(self.x, self.y, cut if segmented else None)
+            if cap["ctx"] is not None:
+                end(None)
+        except BaseException:
+            if cap["ctx"] is not None:
+                cap["ctx"].__exit__(None, None, None)
+            raise
+        self.graph = self.segments[0][0]
+        assert [n for _, n in self.segments] == (STAGE_ORDER if segmented else [None])
+        self.pack_table = engine._pack_tables.get(True)
+        assert self.pack_table is not None and self.pack_table.launches_captured >= 1, \
+            "the captured training step does not contain the conv-weight re-pack"
+        engine.dirty = True                    # the capture itself executed nothing
         engine.use_side_stream = side
 
     def matches(self, x):
         return tuple(x.shape) == self.shape
 
-    def __call__(self, x, y):
+    def pool(self):
+        return self.segments[0][0].pool()
+
+    def __call__(self, x, y, on_stage_done=None):
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
-        self.graph.replay()
+        for g, name in self.segments:          # segment 0 re-packs the conv weights from the parameter arena first
+            g.replay()
+            if name is not None and on_stage_done is not None:
+                on_stage_done(name)
+        self.eng.dirty, self.eng._packed_for_bwd = False, True
         self.eng.m.attach_grads()
         return self.loss, self.logits, self.rank

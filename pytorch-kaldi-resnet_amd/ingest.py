@@ -105,7 +105,15 @@ class NativeTrainLoader:
     """Iterable over (features [B,F,T] pinned, labels [B] int64) batches of one epoch for this rank."""
 
     def __init__(self, scp_file, utt2spkid_file, chunk_size, batch_size, rank=0, world=1, seed=0, threads=4,
-                 drop_last=False, prefetch=2):
+                 drop_last=False, prefetch=2, device=None):
+        """device=None: batches are fresh pageable host tensors (the caller copies them; a copy from pageable memory is
+        staged by the runtime before .cuda() returns, so nothing can overwrite it early).
+        device=cuda:N: the loader owns a ring of PINNED staging buffers and the host->device copy: it issues the copy on
+        its own copy stream (overlapping the previous step's kernels), records an event per ring slot, and the reader
+        thread waits for that event before it refills the slot - the training loop never syncs with the host, so
+        without this guard the reader could overwrite a slot whose asynchronous copy has not executed yet.  Yields
+        device tensors, already ordered after the copy on the consumer's current stream."""
+        self.device = torch.device(device) if device is not None else None
         utt2spk = {}
         for line in open(utt2spkid_file):
             u, s = line.split()
@@ -155,8 +163,10 @@ class NativeTrainLoader:
         rng = np.random.RandomState((self.seed + self.epoch) * 7919 + self.rank)
         F = int(self.table.cols[0])
         q = queue.Queue(maxsize=self.prefetch)
-        ring = [torch.empty(self.bs, F, self.T).pin_memory() if torch.cuda.is_available() else torch.empty(self.bs, F, self.T)
-                for _ in range(self.prefetch + 2)]
+        dev = self.device
+        nslot = self.prefetch + 2
+        ring = [torch.empty(self.bs, F, self.T).pin_memory() for _ in range(nslot)] if dev is not None else None
+        copied = [None] * nslot          # per slot: event recorded after the H2D copy that last read the slot
 
         def producer():
             try:
@@ -167,9 +177,16 @@ class NativeTrainLoader:
                         break
                     rows = self.sample_to_row[sel]
                     starts = [int(rng.randint(0, int(self.table.rows[r]) - self.T + 1)) for r in rows]   # datasets.py:66
-                    buf = ring[k % len(ring)][:len(sel)]
+                    slot = k % nslot
+                    if ring is not None:
+                        ev = copied[slot]
+                        if ev is not None:
+                            ev.synchronize()            # the device has finished reading this pinned buffer
+                        buf = ring[slot][:len(sel)]
+                    else:
+                        buf = torch.empty(len(sel), F, self.T)
                     self.table.read_crop(rows, starts, self.T, buf, self.threads)
-                    q.put((buf, torch.from_numpy(self.labels[sel])))
+                    q.put((slot, buf, torch.from_numpy(self.labels[sel])))
                     k += 1
                 q.put(None)
             except BaseException as e:      # surface reader errors in the training loop
@@ -177,11 +194,26 @@ class NativeTrainLoader:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        copy_stream = torch.cuda.Stream(device=dev) if dev is not None else None
         while True:
             item = q.get()
             if item is None:
                 break
             if isinstance(item, BaseException):
                 raise item
-            yield item
+            slot, buf, lab = item
+            if dev is None:
+                yield buf, lab
+                continue
+            cur = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(copy_stream):
+                xg = buf.to(dev, non_blocking=True)
+                yg = lab.pin_memory().to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            copied[slot] = ev
+            cur.wait_event(ev)
+            xg.record_stream(cur)
+            yg.record_stream(cur)
+            yield xg, yg
         th.join()

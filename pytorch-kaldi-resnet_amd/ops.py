@@ -89,8 +89,13 @@ class PackTable:
             self.key.append((w.data_ptr(), wpk.data_ptr(), transpose, split))
         self.njobs, self.blocks = len(jobs), block0
         self.table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+        self.launches = 0               # eager launches + launches recorded into a hipGraph
+        self.launches_captured = 0
 
     def run(self):
+        self.launches += 1
+        if torch.cuda.is_current_stream_capturing():
+            self.launches_captured += 1
         call("spk_pack_conv_weights_batched", ptr(self.table), self.njobs, self.blocks, stream(), label="spk_pack_conv_weight")
 
 
@@ -281,6 +286,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def _workspace(nbytes, device):
@@ -288,6 +294,8 @@ def _workspace(nbytes, device):
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() * 4 < nbytes:
+        if w is not None:
+            _ws_retired.append(w)       # a captured hipGraph may still hold its address: never hand it back
         w = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
         _ws_cache[key] = w
     return w

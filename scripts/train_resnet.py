@@ -64,8 +64,8 @@ parser.add_argument("--native-reader", action="store_true",
                     help="read training batches with the native C++ ark reader (libspkio: pread of the cropped frames on a "
                          "thread pool into pinned memory) instead of Dataset/DataLoader worker processes; --dataset v1 only")
 parser.add_argument("--no-graph", action="store_true",
-                    help="launch kernels eagerly (stage-bucketed all-reduce overlapped with backward) instead of replaying "
-                         "the step as one hipGraph followed by one flat all-reduce")
+                    help="launch kernels eagerly instead of replaying the step as hipGraph(s); both forms overlap the "
+                         "stage-bucketed gradient all-reduce with backward")
 
 best_acc1 = 0
 
@@ -99,7 +99,9 @@ def main_worker(gpu, ngpus_per_node, args):
     args.gpu = gpu
     print("Use GPU: {} for training".format(args.gpu))
     from pytorch_kaldi_resnet_amd import tiling
-    tiling.AUTOTUNE = True        # like `cudnn.benchmark = True` (reference train_resnet.py:231): tune tiles on first use
+    # like `cudnn.benchmark = True` (reference train_resnet.py:231): tune tiles on first use.  Timing-based, so two runs
+    # may pick different tiles (= summation orders); SPK_AUTOTUNE=0 pins the built-in table for bit-reproducible runs.
+    tiling.AUTOTUNE = os.environ.get("SPK_AUTOTUNE", "1") == "1"
     if args.distributed:
         if args.dist_url == "env://" and args.rank == -1:
             args.rank = int(os.environ["RANK"])
@@ -157,7 +159,7 @@ def main_worker(gpu, ngpus_per_node, args):
         from pytorch_kaldi_resnet_amd.ingest import NativeTrainLoader
         train_loader = NativeTrainLoader(args.train_list, args.utt2spkid, args.max_chunk_size, args.batch_size,
                                          rank=max(args.rank, 0), world=world, seed=args.seed or 0,
-                                         threads=max(1, args.workers))
+                                         threads=max(1, args.workers), device="cuda:%d" % args.gpu)
         train_sampler = train_loader          # set_epoch() reshuffles, like DistributedSampler
     else:
         train_dataset = DS(scp_file=args.train_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
@@ -241,10 +243,12 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
         target = target.cuda(args.gpu, non_blocking=True).long()
         if not args.no_graph and (graphed is None or not graphed.matches(audios)) and audios.size(0) == args.batch_size:
             from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
-            graphed = eng._graphed_step = GraphedTrainStep(eng, audios.size(0), audios.size(2))
+            graphed = eng._graphed_step = GraphedTrainStep(eng, audios.size(0), audios.size(2), segmented=world > 1)
         if not args.no_graph and graphed is not None and graphed.matches(audios):
-            loss, _, rank = graphed(audios, target)          # one hipGraph launch: fwd + CE + bwd
-            reducer.allreduce_all()
+            # hipGraph replay: weight re-pack + fwd + CE + bwd; with world > 1 six stage segments with the stage's
+            # all-reduce enqueued on the communication stream between them (overlaps the remaining backward)
+            loss, _, rank = graphed(audios, target, reducer.on_stage_done if world > 1 else None)
+            reducer.finish()
         else:
             optimizer.zero_grad(set_to_none=True)
             loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if world > 1 else None)

@@ -161,6 +161,40 @@ def test_datasets_balance_and_crop(gold_dir, tmp_path):
         os.chdir(cwd)
 
 
+def test_datasets_match_the_reference_classes(gold_dir):
+    """SequenceDataset / SequenceDataset2 against fixtures produced by the reference's own classes
+    (tools/make_dataset_golden.py: imported scripts/datasets.py with the `numpy.int = int` shim): class-balanced
+    repetition (scripts/datasets.py:23-31), sample order, the per-sample length draw, and - with the global numpy RNG
+    seeded the same way - the very same crops (utterance draw, then crop start: :128-137, :64-68)."""
+    g = np.load(os.path.join(gold_dir, "datasets.npz"))
+    scp, u2s = os.path.join(gold_dir, "io", "unbalanced.scp"), os.path.join(gold_dir, "io", "unbalanced.utt2spkid")
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ds = datasets.SequenceDataset(scp, u2s, [16])
+        assert len(ds) == int(g["v1_len"])
+        np.testing.assert_array_equal(ds.labels, g["v1_labels"])
+        assert [str(r) for r in ds.rxfiles] == [str(r) for r in g["v1_rxfiles"]]
+        for i in g["v1_idx"]:
+            np.random.seed(100 + int(i))
+            x, y = ds[int(i)]
+            np.testing.assert_array_equal(x, g["v1_x%d" % i])
+            assert int(y) == int(g["v1_y%d" % i]) and x.dtype == np.float32
+        np.random.seed(5)
+        dsv = datasets.SequenceDataset(scp, u2s, [12, 20])
+        np.testing.assert_array_equal(dsv.seq_len, g["v1_var_seq_len"])
+        ds2 = datasets.SequenceDataset2(scp, u2s, 14)
+        assert len(ds2) == int(g["v2_len"]) and ds2.repetition == int(g["v2_repetition"])
+        np.testing.assert_array_equal(ds2.labels, g["v2_labels"])
+        for i in g["v2_idx"]:
+            np.random.seed(200 + int(i))
+            x, y = ds2[int(i)]
+            np.testing.assert_array_equal(x, g["v2_x%d" % i])
+            assert int(y) == int(g["v2_y%d" % i])
+    finally:
+        os.chdir(cwd)
+
+
 @pytest.mark.parametrize("loss,arch", [("AAM", "resnet34"), ("softmax", "resnet34"), ("AAM-v1", "resnet34"),
                                        ("AAM", "resnet101")])
 def test_state_dict_matches_reference_keys(gold_dir, loss, arch):

@@ -27,6 +27,18 @@ pytestmark = pytest.mark.gpu
 from oracle import spk_oracle as O  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
+def loss_curve_tol(gold_dir, name):
+    """|loss - recorded reference loss| budget per SGD step of the recorded 5-step curves.  SURVEY.md section 8c asks for
+    1e-4 at step 0 and <= 1e-3 by step 5; the reference itself does not meet the latter against ITSELF: with every input
+    value moved by at most one unit in the last place (what another correct fp32 summation order does) its own step-4 loss
+    moves by up to 9.5e-3, and its fp64 run differs from its fp32 run by 4.5e-3 (tools/ref_sensitivity.py, imported
+    reference, recorded in tests/golden/ref_sensitivity.json).  Budget: 1e-4 at step 0 (well conditioned), then 3x the
+    larger of those two measured self-distances of the reference, never below 1e-4."""
+    ent = json.load(open(os.path.join(gold_dir, "ref_sensitivity.json")))["cases"][name]
+    own = [max(a, abs(b)) for a, b in zip(ent["perturb_ulp"]["max_abs_dloss"], ent["fp64_minus_recorded"])]
+    return [1e-4] + [max(1e-4, 3.0 * v) for v in own[1:]]
+
+
 CASES = ["c1_r34_aam", "r34_aam_t203", "r34_aam_t300", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"]
 
 
@@ -104,55 +116,109 @@ def test_forward_parity(P, gold_dir, name):
             assert int(sd[key[4:] + ".num_batches_tracked"]) == int(g[key])
 
 
-@pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"])
+def hip_step_with_masks(m, xg, yg):
+    """forward + CE + backward through the engine, also returning the ReLU masks the HIP forward chose, in the call
+    order of the reference forward (scripts/model.py:250, 48-64 / 115-135 per block, head :361-363): the masks the
+    backward kernels differentiate with.  Inner masks come from the same fused multiply-add the kernels use
+    (spk_bn_apply); block-output masks from the stored block outputs."""
+    from pytorch_kaldi_resnet_amd import ops
+    eng = m.engine()
+    m.attach_grads()
+    for p in m.parameters():
+        p.grad = None
+    with torch.no_grad():
+        logits, saved = eng.forward_train(xg.contiguous(), yg)
+        nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()      # noqa: E731
+        masks = [nchw(saved["blocks"][0]["x"])]
+        for b, rec in zip(eng.blocks, saved["blocks"]):
+            for raw, bn in zip(rec["raws"][:-1], b.bns[:-1]):
+                masks.append(nchw(ops.bn_apply(raw, bn.t4[2], bn.t4[3], relu=True)))
+            masks.append(nchw(rec["out"]))
+        if "h" in saved["head"]:
+            masks.append((saved["head"]["h"] > 0).cpu())
+        loss_row, dl, _ = ops.softmax_ce(logits, yg, grad_scale=1.0 / logits.shape[0])
+        loss = float(ops.mean(loss_row))
+    eng.backward(saved, dl)
+    torch.cuda.synchronize()
+    return loss, {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}, masks
+
+
+@pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam", "r34_aam_t300"])
 def test_backward_parity(P, gold_dir, name):
+    """Gradients against the fp64 oracle.
+
+    (1) Arithmetic: the HIP gradient against the fp64 gradient of the SAME piecewise-linear function - the oracle forward
+        replayed with the ReLU masks the HIP forward chose (oracle/masked.py).  The CPU fp32 oracle is held to the same
+        yardstick with its own masks; the HIP error must be within 3x of it, no additive slack (measured: about 1x).
+    (2) Forward agreement: the fraction of ReLU masks that differ from the fp64 forward's is at the fp32 rounding level
+        (a few elements per network, like the CPU fp32 path's) - each differing element is a legitimate subgradient
+        choice at |z| ~ 1e-5 but moves the free-running gradient comparison by ~1/sqrt(N) of a layer's gradient, which is
+        why (3) the free-running comparison keeps a budget derived from the flip count instead of a constant."""
+    from oracle import masked
     meta = json.load(open(os.path.join(gold_dir, name + ".json")))
     g = np.load(os.path.join(gold_dir, name + ".npz"))
     m, npst = build(P, meta)
     x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
     xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     m.train()
-    logits = m(xg, yg)
-    loss = torch.nn.functional.cross_entropy(logits, yg)
-    loss.backward()
     names = [n for n, _ in m.named_parameters()]
     assert names == meta["param_names"]
-    hip = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
-    # oracle in fp32 and fp64 on the same inputs
+    loss_hip, hip, masks_hip = hip_step_with_masks(m, xg, yg)
     kw = dict(pooling=meta["pooling"], loss=meta["loss"], arch=meta["arch"])
 
-    def oracle_grads(dtype):
+    def oracle_own(dtype):
         st = O.to_torch_state(npst)
         st = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
         keys = O.trainable_keys(st)
         for k in keys:
             st[k].requires_grad_(True)
-        lo = O.forward(st, torch.from_numpy(x).to(dtype), torch.from_numpy(y), train=True, **kw)
+        lo, masks = masked.record_masks(st, torch.from_numpy(x).to(dtype), torch.from_numpy(y), **kw)
         lv = O.cross_entropy(lo, torch.from_numpy(y))
         gs = torch.autograd.grad(lv, [st[k] for k in keys])
-        return {k: v.double() for k, v in zip(keys, gs)}
+        return {k: v.double() for k, v in zip(keys, gs)}, masks
 
-    g32, g64 = oracle_grads(torch.float32), oracle_grads(torch.float64)
+    g32, masks32 = oracle_own(torch.float32)
+    g64, masks64 = oracle_own(torch.float64)
+    assert [tuple(a.shape) for a in masks_hip] == [tuple(a.shape) for a in masks64]
+    _, ref_hip = masked.grads(npst, x, y, masks=masks_hip, **kw)      # fp64 yardstick under the HIP forward's masks
+    _, ref_32 = masked.grads(npst, x, y, masks=masks32, **kw)         # ... and under the CPU fp32 forward's masks
 
     def flat(d):
         return torch.cat([d[n].reshape(-1) for n in names])
 
-    f64 = flat(g64)
-    e_oracle = float((flat(g32) - f64).norm() / f64.norm())
-    e_hip = float((flat(hip) - f64).norm() / f64.norm())
-    print("grad error vs fp64: oracle-fp32 %.3e  hip %.3e" % (e_oracle, e_hip))
-    assert e_hip <= 3.0 * e_oracle + 2e-2
-    # head parameters are well conditioned
-    for n in names:
-        if n.startswith("fc1.weight") or n == "last.weight":
-            e = float((hip[n] - g64[n]).norm() / g64[n].norm())
-            assert e < 5e-4, (n, e)
+    def rel(a, b):
+        return float((flat(a) - flat(b)).norm() / flat(b).norm())
+
+    # (1) arithmetic of the backward, mask choices factored out
+    e_hip, e_cpu = rel(hip, ref_hip), rel(g32, ref_32)
+    # per tensor, relative to that tensor's gradient norm - with a floor of 1e-3 of the largest tensor norm so that
+    # analytically-zero gradients (fc1.bias in front of the head's BatchNorm1d) are judged on an absolute scale
+    floor = 1e-3 * max(float(ref_hip[n].norm()) for n in names)
+    worst = max(float((hip[n] - ref_hip[n]).norm() / max(float(ref_hip[n].norm()), floor)) for n in names)
+    worst_cpu = max(float((g32[n] - ref_32[n]).norm() / max(float(ref_32[n].norm()), floor)) for n in names)
+    print("same-mask gradient error vs fp64: hip %.3e (worst tensor %.3e)  cpu-fp32 %.3e (worst tensor %.3e)" % (
+        e_hip, worst, e_cpu, worst_cpu))
+    assert e_hip <= 3.0 * e_cpu, (e_hip, e_cpu)
+    assert worst <= 3.0 * worst_cpu + 1e-5, (worst, worst_cpu)
+    # (2) mask agreement with the fp64 forward
+    n_el = sum(a.numel() for a in masks64)
+    flips_hip = sum(int((a != b).sum()) for a, b in zip(masks_hip, masks64))
+    flips_cpu = sum(int((a != b).sum()) for a, b in zip(masks32, masks64))
+    print("ReLU masks differing from the fp64 forward: hip %d, cpu-fp32 %d of %d" % (flips_hip, flips_cpu, n_el))
+    assert flips_hip <= 3 * flips_cpu + 2e-6 * n_el + 4     # Poisson counts: mean ~ (fp32 forward error ~1e-5) x density x N
+    # (3) free-running comparison (each path with its own masks): budget = the fp32 oracle's own error + what the
+    # differing masks can move (rms over the layers they sit in is bounded by sqrt(flips / smallest layer size))
+    smallest = min(a.numel() for a in masks64)
+    e_free, e_free_cpu = rel(hip, g64), rel(g32, g64)
+    print("free-running gradient error vs fp64: hip %.3e cpu-fp32 %.3e" % (e_free, e_free_cpu))
+    assert e_free <= 3.0 * e_free_cpu + 2.0 * (flips_hip / smallest) ** 0.5 + 3.0 * e_hip
     # golden norms recorded from the reference itself
     # (2 %, or 1.5x the fp32 oracle's own whole-gradient error against fp64 where that is larger: ResNet-101 at batch 2)
-    tol = max(2e-2, 1.5 * e_oracle)
+    tol = max(2e-2, 1.5 * e_free_cpu)
     for i, n in enumerate(names):
         ref = float(g["grad_norm"][i])
         assert abs(float(hip[n].norm()) - ref) <= tol * ref + 1e-5, n
+    assert abs(loss_hip - float(g["loss_train"])) < 5e-4
 
 
 def test_fused_step_equals_autograd_path(P, gold_dir):
@@ -211,6 +277,54 @@ def test_graphed_step_equals_eager(P, gold_dir):
     assert int(m2.state_dict()["res.bn1.num_batches_tracked"]) == int(m1b.state_dict()["res.bn1.num_batches_tracked"]) + 1
 
 
+def test_graph_replay_trains_on_updated_weights(P, gold_dir):
+    """graph -> SGD -> graph -> ... must be the eager step -> SGD -> step -> ... bit for bit (reference
+    scripts/train_resnet.py:316-328: every forward runs on the weights optimizer.step() just wrote).  A captured step
+    that does not re-pack the convolution weights keeps training on the weights of capture time: the losses then stop
+    matching after the first update.  lr is large enough (1e-2) for every step to move the loss visibly."""
+    from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
+    from pytorch_kaldi_resnet_amd.optim import FlatSGD
+    meta = json.load(open(os.path.join(gold_dir, "c1_r34_aam.json")))
+    g = np.load(os.path.join(gold_dir, "c1_r34_aam.npz"))
+    tol = loss_curve_tol(gold_dir, "c1_r34_aam")
+    batches = []
+    for s in range(5):
+        xs, ys = W.make_input(meta["seed"] + 1 + s, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+        batches.append((torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()))
+    for lr, wd in ((1e-2, 5e-4), (meta["lr"], meta["wd"])):
+        me, _ = build(P, meta)
+        mg, _ = build(P, meta)
+        me.train()
+        mg.train()
+        oe = FlatSGD(me, lr, momentum=0.9, weight_decay=wd)
+        og = FlatSGD(mg, lr, momentum=0.9, weight_decay=wd)
+        step = GraphedTrainStep(mg.engine(), meta["batch"], meta["frames"], warmup=1)
+        assert torch.equal(mg.flat_parameters(), me.flat_parameters())      # building the graph left the weights alone
+        le, lg = [], []
+        for s, (xs, ys) in enumerate(batches):
+            oe.zero_grad(set_to_none=True)
+            l1, _, _ = me.engine().loss_and_grad(xs, ys)
+            l2, _, _ = step(xs, ys)
+            assert float(l1) == float(l2), (lr, s, float(l1), float(l2))
+            assert torch.equal(me.flat_grads(), mg.flat_grads()), (lr, s)
+            oe.step()
+            og.step()
+            assert torch.equal(me.flat_parameters(), mg.flat_parameters()), (lr, s)
+            le.append(float(l1))
+            lg.append(float(l2))
+        print("lr %g: graph losses %s" % (lr, lg))
+        if lr == 1e-2:
+            # the update is visible: same batch again gives a different loss than before the 5 steps
+            l_again, _, _ = step(*batches[0])
+            assert abs(float(l_again) - lg[0]) > 1e-3
+        else:
+            # at the fixture's own lr the graph path meets the reference's recorded curve (same budget as the eager path)
+            for i, (a, b) in enumerate(zip(lg, g["loss_curve"])):
+                assert abs(a - b) <= tol[i], (i, a, b)
+        # every replay re-packed: the packed weights now in use equal a fresh pack of the weights of the LAST forward
+        assert step.pack_table.launches_captured == 1
+
+
 @pytest.mark.parametrize("name", ["c1_r34_aam", "r34_softmax_mean_f40"])
 def test_sgd_loss_curve(P, gold_dir, name):
     from pytorch_kaldi_resnet_amd.optim import FlatSGD
@@ -230,10 +344,8 @@ def test_sgd_loss_curve(P, gold_dir, name):
         opt.step()
         losses.append(float(loss))
     print("loss curve", losses, list(g["loss_curve"]))
-    # Training this network on 3-4 utterances is chaotic: perturbing the CPU reference's own input by 1e-6 moves
-    # its loss by 2e-5 / 2e-4 / 1e-3 / 5e-3 (relative) at steps 1..4 (tools/make_golden.py notes),
-    # and any change of summation order (tile shapes) is such a perturbation.  Per-step budget accordingly:
-    tol = [1e-4, 2e-3, 6e-3, 2e-2, 5e-2][:len(losses)]
+    tol = loss_curve_tol(gold_dir, name)[:len(losses)]
+    print("per-step budget", tol, "deviation", [abs(a - b) for a, b in zip(losses, g["loss_curve"])])
     for i, (a, b) in enumerate(zip(losses, g["loss_curve"])):
         assert abs(a - b) <= tol[i], (i, a, b)
     x, _ = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])

@@ -137,3 +137,47 @@ def test_cosine_lr_matches_torch_scheduler():
         assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(e, 30, 0.1, 1e-4)) < 1e-9
         opt.step()
         sch.step()
+
+
+def test_masked_oracle_reproduces_the_plain_oracle(gold_dir):
+    """oracle/masked.py (the same-mask yardstick of the GPU gradient tests): replaying the forward with the masks it chose
+    itself gives the same logits and the same gradient as the plain oracle - for both block kinds and the BN1d head."""
+    from oracle import masked
+    for arch, loss, pooling in (("resnet18", "AAM-v1", "mean+std"), ("resnet50", "softmax", "mean")):
+        S, Fd, T, B = 5, 24, 40, 3
+        npst = W.make_state(31, S, Fd, pooling, loss, arch)
+        x, y = W.make_input(32, B, Fd, T, S)
+        st = O.to_torch_state(npst)
+        keys = O.trainable_keys(st)
+        for k in keys:
+            st[k].requires_grad_(True)
+        lo, masks = masked.record_masks(st, torch.from_numpy(x), torch.from_numpy(y), pooling, loss, arch)
+        g_plain = torch.autograd.grad(O.cross_entropy(lo, torch.from_numpy(y)), [st[k] for k in keys])
+        nrelu = {"resnet18": 1 + 8 * 2, "resnet50": 1 + 16 * 3}[arch] + 1      # stem + per block + head BN1d/ReLU
+        assert len(masks) == nrelu
+        lv, g_masked = masked.grads(npst, x, y, pooling, loss, arch, masks, dtype=torch.float32)
+        assert abs(lv - float(O.cross_entropy(lo, torch.from_numpy(y)))) < 1e-6
+        for k, a in zip(keys, g_plain):
+            assert float((g_masked[k] - a.double()).norm()) <= 1e-6 * float(a.norm()) + 1e-9, k
+        # flipping one mask element changes the gradient: the masks really steer the backward
+        masks[3] = masks[3].clone()
+        idx = tuple(int(v[0]) for v in torch.nonzero(masks[3], as_tuple=True))
+        masks[3][idx] = False
+        _, g_flip = masked.grads(npst, x, y, pooling, loss, arch, masks, dtype=torch.float32)
+        assert any(float((g_flip[k] - g_masked[k]).norm()) > 0 for k in keys)
+
+
+def test_reference_sensitivity_fixture(gold_dir):
+    """tests/golden/ref_sensitivity.json (tools/ref_sensitivity.py: the imported reference against itself) backs the
+    loss-curve budget of the GPU tests: well formed, and it says what DESIGN.md says it says."""
+    import json
+    d = json.load(open(os.path.join(gold_dir, "ref_sensitivity.json")))
+    for name in ("c1_r34_aam", "r34_softmax_mean_f40"):
+        ent = d["cases"][name]
+        rec = np.load(os.path.join(gold_dir, name + ".npz"))["loss_curve"]
+        assert np.allclose(ent["recorded"], rec)
+        n = len(rec)
+        assert len(ent["fp64_minus_recorded"]) == n and len(ent["perturb_ulp"]["max_abs_dloss"]) == n
+        assert ent["perturb_ulp"]["max_abs_dloss"][0] < 1e-4 and abs(ent["fp64_minus_recorded"][0]) < 1e-4
+    c1 = d["cases"]["c1_r34_aam"]
+    assert c1["perturb_ulp"]["max_abs_dloss"][4] > 1e-3      # the reference does not track itself to 1e-3 at step 4

@@ -117,3 +117,42 @@ def test_train_decode_score_pipeline(tmp_path):
     eer_h = float(r.stdout.strip().rstrip("%")) / 100
     print("EER hip %.4f oracle %.4f" % (eer_h, eer_o))
     assert abs(eer_h - eer_o) <= 0.005 + 1e-9
+
+
+def test_resume_continues_the_uninterrupted_run(tmp_path):
+    """--resume (reference scripts/train_resnet.py:209-229): epoch counter, weights, BatchNorm buffers, momentum buffers and
+    the learning-rate schedule come back from the checkpoint - a run resumed from checkpoint_epoch0 must write the same
+    checkpoint_epoch1 as the uninterrupted 2-epoch run (the default --lr-final 1e-4 is also what the resume path
+    hard-codes, :225).  Tile autotuning is pinned off: it is timing-based and would change summation orders between runs."""
+    d = str(tmp_path)
+    n_spk = _make_data(d)
+    env = dict(os.environ, PYTHONPATH=ROOT, SPK_AUTOTUNE="0")
+
+    def run(logdir, extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_resnet.py"), "--gpu", "0", "--workers", "0",
+                            "--batch-size", "16", "--print-freq", "1", "--arch", "resnet34", "--input-dim", "80",
+                            "--loss-type", "AAM", "--pooling", "mean+std", "--epochs", "2", "--lr", "0.01", "--wd", "5e-4",
+                            "--max-chunk-size", "200", "--train-list", os.path.join(d, "train.scp"),
+                            "--cv-list", os.path.join(d, "cv.scp"), "--spk-num", str(n_spk),
+                            "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "7", "--native-reader",
+                            "--log-dir", os.path.join(d, logdir)] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout
+
+    run("full", [])
+    out = run("resumed", ["--resume", os.path.join(d, "full", "checkpoint_epoch0.pth.tar")])
+    assert "=> loaded checkpoint" in out and "(epoch 1)" in out and "Epoch: [0][" not in out and "Epoch: [1][" in out
+    a = torch.load(os.path.join(d, "full", "checkpoint_epoch1.pth.tar"), map_location="cpu", weights_only=True)
+    b = torch.load(os.path.join(d, "resumed", "checkpoint_epoch1.pth.tar"), map_location="cpu", weights_only=True)
+    first = torch.load(os.path.join(d, "full", "checkpoint_epoch0.pth.tar"), map_location="cpu", weights_only=True)
+    assert a["epoch"] == b["epoch"] == 2
+    moved = 0
+    for k, v in a["state_dict"].items():
+        assert torch.equal(v, b["state_dict"][k]), k
+        moved += int(not torch.equal(v, first["state_dict"][k]))
+    assert moved > 200                       # epoch 1 really trained (every tensor but a few moved)
+    assert float(a["best_acc1"]) == float(b["best_acc1"])
+    sa, sb = a["optimizer"], b["optimizer"]
+    assert sa["param_groups"][0]["lr"] == pytest.approx(sb["param_groups"][0]["lr"], rel=1e-12)
+    for i, ent in sa["state"].items():
+        assert torch.equal(ent["momentum_buffer"], sb["state"][i]["momentum_buffer"]), i

@@ -35,7 +35,11 @@ for k in sorted(set(fetch) | set(write)):
     wb = 1024.0 * sum(w) / len(w)
     out[k] = {"launches": len(f), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
               "hbm_bytes_per_launch": fb + wb}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 "
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pytorch-kaldi-resnet_amd"))
+import build as _build  # noqa: E402
+
+json.dump({"csrc_fingerprint": _build.csrc_fingerprint(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 "
                      "--warmup 1 --no-cpu-baseline --no-roofline`; FETCH_SIZE doubled per the gfx950 note",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out), "kernels")
