@@ -45,6 +45,8 @@ def mfma_peak(kernel_label):
     terms = 0
     if kernel_label.startswith("conv_mfma_kernel") and len(inner) == 4:
         terms = int(inner[3])
+    elif kernel_label.startswith("conv_ws_kernel") and len(inner) == 5:
+        terms = int(inner[4])
     elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 4:
         terms = int(inner[2])
     if terms:

@@ -61,6 +61,7 @@ struct ConvArgs {
     int tap_off[9];   // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
     int tap_w[9];     // weight tap index
     int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
+    int tap_boff[9];  // wave-specialised kernel: float offset of (tap, channel plane 0) in the bf16-split packed weights
     int kc;           // channel planes (of 32) staged per barrier: > 1 only for single-tap (1x1) convolutions, whose K loop
                       // per 32-channel chunk is too short to amortise a staging phase
 };

@@ -22,6 +22,8 @@
 
 // bf16-split instantiations live in their own translation unit (conv_split.hip)
 int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, int split, hipStream_t st);
+// wave-specialised persistent form (conv_ws.hip)
+int spk_launch_conv_ws(const ConvArgs& a, int MT, int NT, int WC, int split, int lp4, hipStream_t st);
 
 template <int MT, int NT>
 static int launch_conv(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
@@ -48,13 +50,16 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(in && wpk && out, "spk_conv_mfma: null pointer");
     SPK_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "spk_conv_mfma: empty tensor");
     SPK_REQUIRE(Cin % 32 == 0 && Cin > 0, "spk_conv_mfma: Cin=%d must be a multiple of 32", Cin);
-    SPK_REQUIRE(NT >= 1 && Cout % (32 * NT) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT (NT=%d)", Cout, NT);
+    // wave-specialised kernel: bits 8-9 of flags = log2 of WC, the number of consumer-wave channel groups (1, 2, 4)
+    const int ws_wc = (flags & SPK_CONV_WS) ? 1 << ((flags >> 8) & 3) : 1;
+    SPK_REQUIRE(ws_wc <= 4, "spk_conv_mfma: bad wave layout");
+    SPK_REQUIRE(NT >= 1 && Cout % (32 * NT * ws_wc) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT*WC (NT=%d, WC=%d)", Cout, NT, ws_wc);
     SPK_REQUIRE(ntaps >= 1 && ntaps <= 9, "spk_conv_mfma: ntaps=%d out of range", ntaps);
     SPK_REQUIRE(split == 0 || split == 6 || split == 9, "spk_conv_mfma: split=%d (0 = fp32 operands, 6 / 9 = bf16 cross terms)", split);
     const int ck = split ? SPK_SPLIT_CK : 32;                     // channels per staged plane
     const int lp4 = split ? (3 * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
     SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
-    SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT, "spk_conv_mfma: tile %dx%d exceeds 128*MT (MT=%d)", TH, TW, MT);
+    SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT / ws_wc, "spk_conv_mfma: tile %dx%d exceeds %d pixels (MT=%d)", TH, TW, 128 * MT / ws_wc, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
     SPK_REQUIRE((OH - 1) * OS + ooy < OHf && (OW - 1) * OS + oox < OWf, "spk_conv_mfma: logical grid exceeds the output tensor");
     SPK_REQUIRE((long long)B * OHf * OWf * Cout < 2147483647LL && (long long)B * IH * IW * Cin < 2147483647LL * 4,
@@ -109,14 +114,23 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
         }
     }
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
-    a.ntaps = ntaps * kc; a.ncg = Cout / (32 * NT);
+    a.ntaps = ntaps * kc; a.ncg = Cout / (32 * NT * ws_wc);
     a.nblocks = B * a.tiles_y * a.tiles_x * a.ncg;
     a.flags = flags;
     size_t lds_bytes = (size_t)kc * a.halo_h * a.halo_w * lp4 * 16;
     const size_t red_bytes = (size_t)4 * 32 * (NT * 32 + 4) * sizeof(float);   // epilogue transpose slabs, one per wave
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
-    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);
+    SPK_REQUIRE((flags & SPK_CONV_WS) || lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (flags & SPK_CONV_WS) {
+        SPK_REQUIRE(split != 0 && kc == 1 && ntaps == 9, "spk_conv_mfma: the wave-specialised kernel needs bf16-split operands, 9 taps and kc = 1");
+        for (int t = 0; t < 9; ++t) {
+            const long long off = (long long)a.tap_w[t] * (Cin >> 4) * 3 * (Cout >> 5) * 256;     // [tap][Cin/16][term][Cout/32][256 floats]
+            SPK_REQUIRE(off < 2147483647LL, "spk_conv_mfma: packed weight offset overflows");
+            a.tap_boff[t] = (int)off;
+        }
+        return spk_launch_conv_ws(a, MT, NT, ws_wc, split, lp4, st);
+    }
     if (split) return spk_launch_conv_split(a, lds_bytes, MT, NT, split, st);
 #define CASE(M, N) if (MT == M && NT == N) return launch_conv<M, N>(a, lds_bytes, st)
     CASE(1, 1); CASE(2, 1); CASE(3, 1); CASE(4, 1);

@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import hip, tiling
-from .hip import (EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
+from .hip import (CONV_WS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
                   MASK_RAW,
                   call, ptr, stream)
 
@@ -47,6 +47,15 @@ def conv_out_hw(h, w, ksize, stride):
 # forward of a model (or mark its engine dirty).
 MFMA_MODES = {"f32": 0, "bf16x6": 6, "bf16x9": 9}
 SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "bf16x6")]
+
+
+# wave-specialised (producer / consumer, persistent) convolution kernel, csrc/conv_ws_kernel.h: opt-in (SPK_CONV_WS=1).
+# Measured on MI355X: +5..18 % per launch on fresh random operands (tools/ws_check.py), but no gain inside the training
+# step (bench.py: 78.3 ms with it on the 64..256-channel layers, 77.6 ms without) - the step is power-limited, the
+# matrix pipe is ~65 % busy at a 1.9 GHz clock either way - so conv_mfma_kernel stays the default.
+WS_CONV = os.environ.get("SPK_CONV_WS", "0") == "1"
+WS_MIN_TAPS = int(os.environ.get("SPK_WS_MIN_TAPS", "9"))
+WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
 def split_for(ksize):
@@ -113,6 +122,13 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     if tiling.AUTOTUNE and key not in (tiling.FORCE_CONV_SPLIT if split else tiling.FORCE_CONV) and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split)
     TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0, split=split)
+    # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
+    # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
+    ws, WC = None, 1
+    if split and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
+        ws = WS_FORCE or tiling.ws_tile(*key)
+    if ws is not None:
+        TH, TW, MT, NT, WC = ws
     # single-tap (1x1) convolutions stage several 32-channel planes per barrier: their K loop per plane is only 4 MFMA groups
     kc = 1
     if len(taps) == 1:
@@ -122,6 +138,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
                 kc = cand
                 break
     flags = 0
+    if ws is not None:
+        flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
     if in_affine is not None:
         flags |= IN_AFFINE_RELU
     if epi_affine is not None:
@@ -148,7 +166,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         assert bn_bwd[0].shape == out.shape and (bn_bwd[1] is None or bn_bwd[1].shape == out.shape)
     if want_stats:
         flags |= EPI_STATS
-        ntile = 4 * B * (-(-OH // TH)) * (-(-OW // TW))      # one partial row per wave
+        ntile = (4 // WC) * B * (-(-OH // TH)) * (-(-OW // TW))      # one partial row per wave (per pixel group of waves)
         stats = torch.empty(ntile, Cout, 2, device=x.device, dtype=torch.float32)
     call("spk_conv_mfma", ptr(x), ptr(wpk), ptr(out),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
@@ -161,7 +179,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if (bn_bwd and bn_mask is None) else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, stream(),
-         label="conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
+         label=("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
+         else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
     return stats
 

@@ -24,6 +24,7 @@ WGRAD_MAX_TILE = {1: 128, 2: 64, 4: 32}
 FORCE_CONV = {}
 FORCE_CONV_SPLIT = {}     # the same launch shapes in the bf16-split operand mode (112 B of LDS per pixel, faster MFMA phase)
 FORCE_WGRAD = {}
+FORCE_CONV_WS = {}        # wave-specialised kernel (csrc/conv_ws_kernel.h): key -> (TH, TW, MT, NT, WC)
 FORCE_WGRAD_SPLIT = {}    # weight-gradient tiles of the bf16-split kernel (K = 16 pixels per MFMA: tiles of 16 k pixels pad least)
 
 
@@ -37,6 +38,8 @@ def _load_table():
             FORCE_CONV[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("conv_split", {}).items():
             FORCE_CONV_SPLIT[tuple(int(x) for x in k.split(","))] = tuple(v)
+        for k, v in t.get("conv_ws", {}).items():
+            FORCE_CONV_WS[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("wgrad", {}).items():
             FORCE_WGRAD[tuple(int(x) for x in k.split(","))] = tuple(v)
         for k, v in t.get("wgrad_split", {}).items():
@@ -86,6 +89,68 @@ def wgrad_candidates(OH, OW, Cin, Cout, ksize, stride, per_config=4):
         c.sort()
         out += [(TH, TW, WN) for _, TH, TW in c[:per_config]]
     return out
+
+
+# wave layouts compiled into conv_ws.hip: (MT, NT, WC); a block covers (4 // WC) * MT * 32 pixels x WC * NT * 32 channels
+WS_LAYOUTS = [(2, 1, 1), (4, 1, 1), (3, 2, 1), (3, 1, 2), (6, 1, 2), (3, 1, 4), (6, 1, 4)]
+WS_LDS_BYTES = 160 * 1024
+# measured in the training step (bench.py instrumented pass, MI355X): the producer/consumer kernel wins on the 64..256-channel
+# layers (+5..15 %), loses on the 32-channel layer, whose launches are HBM-bound (one CU-resident workgroup hides less latency)
+WS_MIN_COUT = int(_os.environ.get("SPK_WS_MIN_COUT", "64"))
+
+
+def ws_lds_bytes(TH, TW, IS, kspan_y, kspan_x, NT):
+    """two ring slots of the halo tile + one epilogue slab per consumer wave (spk_conv_ws_lds_bytes)"""
+    halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
+    return 2 * halo * SPLIT_PIX_BYTES + 4 * 32 * (NT * 32 + 4) * 4 + 128
+
+
+def ws_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_layout=4):
+    """Candidate (TH, TW, MT, NT, WC) for the wave-specialised kernel: per compiled wave layout the best-filled tiles."""
+    out = []
+    for MT, NT, WC in WS_LAYOUTS:
+        if Cout % (32 * NT * WC):
+            continue
+        cap = (4 // WC) * MT * 32
+        best = []
+        for TH in range(1, min(OH, cap) + 1):
+            for TW in range(1, min(OW, cap // TH) + 1):
+                if ws_lds_bytes(TH, TW, IS, kspan_y, kspan_x, NT) > WS_LDS_BYTES:
+                    continue
+                ty, tx = -(-OH // TH), -(-OW // TW)
+                halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
+                best.append((-(OH * OW) / (ty * tx * cap), halo / (TH * TW), TH, TW))
+        best.sort()
+        out += [(TH, TW, MT, NT, WC) for _, _, TH, TW in best[:per_layout]]
+    return out
+
+
+@lru_cache(maxsize=None)
+def _ws_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
+    """Cost model: MFMA time of the padded tiles + weight-fragment loads (1 / MT per MFMA) + staging of the halo per
+    channel group.  Returns None when the map is too small to fill even the smallest layout reasonably."""
+    if Cout < WS_MIN_COUT:
+        return None
+    best = None
+    for TH, TW, MT, NT, WC in ws_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_layout=3):
+        cap = (4 // WC) * MT * 32
+        ty, tx = -(-OH // TH), -(-OW // TW)
+        ncg = Cout // (32 * NT * WC)
+        halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
+        mfma = cap * WC * NT * ntaps                      # per 16-channel chunk, in units of 32x32 tiles x taps
+        cost = ty * tx * ncg * (mfma * (1.0 + 0.35 / MT) + halo * 0.9 + 60.0)
+        if best is None or cost < best[0]:
+            best = (cost, (TH, TW, MT, NT, WC), (OH * OW) / (ty * tx * cap))
+    if best is None or best[2] < 0.5:
+        return None
+    return best[1]
+
+
+def ws_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
+    key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
+    if key in FORCE_CONV_WS:
+        return FORCE_CONV_WS[key]
+    return _ws_tile(*key)
 
 
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):

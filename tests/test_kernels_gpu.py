@@ -186,6 +186,58 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
     assert e < 3e-5, "wgrad accumulate %g" % e
 
 
+@pytest.mark.parametrize("layout", [(2, 1, 1), (4, 1, 1), (3, 2, 1), (3, 1, 2), (6, 1, 2), (3, 1, 4), (6, 1, 4)])
+@pytest.mark.parametrize("shape", [(2, 128, 11, 23, 1), (3, 128, 20, 27, 2)])
+def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape):
+    """csrc/conv_ws_kernel.h (producer / consumer waves, persistent blocks, LDS ring) against conv_mfma_kernel on ragged
+    maps - tiles that overhang both edges, more tiles than blocks and fewer: forward (stride 1 and 2, fused input
+    BN+ReLU, BN statistics), plain data gradient with shortcut add, and the fused BatchNorm-backward data gradient with
+    sign masks, side output and BN-backward statistics.  Same MFMA order per accumulator => the convolution outputs are
+    bit-identical; the per-wave statistics rows are grouped differently, so they are compared after reduction."""
+    MT, NT, WC = layout
+    B, C, H, Wd, stride = shape
+    old = (ops.SPLIT, ops.WS_CONV, ops.WS_FORCE)
+    ops.SPLIT = 6
+    try:
+        tile = (5, 12, MT, NT, WC)       # 60 pixels: fits the smallest layout (96), leaves every layout's padding rows idle
+        torch.manual_seed(7)
+        x = torch.randn(B, H, Wd, C, device="cuda")
+        w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
+        wpk, wpk_t = ops.pack_conv_weight(w), ops.pack_conv_weight(w, True)
+        sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+        OH, OW = ops.conv_out_hw(H, Wd, 3, stride)
+        dy = torch.randn(B, H, Wd, C, device="cuda")
+        raw, raw_p, dout = (torch.randn(B, H, Wd, C, device="cuda") for _ in range(3))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        m1 = torch.randint(-2 ** 31, 2 ** 31 - 1, (B * H * Wd * (C // 32),), device="cuda", dtype=torch.int32, generator=g)
+        m2 = torch.randint(-2 ** 31, 2 ** 31 - 1, (B * H * Wd * (C // 32),), device="cuda", dtype=torch.int32, generator=g)
+        bn4 = torch.stack([torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5,
+                           torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1])
+        coef = torch.stack([torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.01,
+                            torch.randn(C, device="cuda") * 0.01])
+        res = {}
+        for ws in (False, True):
+            ops.WS_CONV, ops.WS_FORCE = ws, (tile if ws else None)
+            out, st = ops.conv_fwd(x, wpk, C, 3, stride, in_affine=(sc, sh), stats=True)
+            e2 = torch.rand(2, C, device="cuda") + 0.5
+            res_in = out * 0.5
+            out2, _ = ops.conv_fwd(x, wpk, C, 3, stride, epi_affine=(e2[0], e2[1]), epi_add=res_in, relu=True)
+            draw = torch.full_like(raw, 7.0)
+            dx, part = ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, Wd), add=dout, add_mask=m2, bn_bwd=(raw_p, None, bn4, m2),
+                                      in_bnbwd=(raw, None, bn4, coef, m1), side=(draw, None))
+            dxp = ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, Wd), add=dout)
+            res[ws] = (out, st, out2, dx, draw, part, dxp)
+        a, b = res[False], res[True]
+        for i in (0, 3, 4, 6):
+            assert torch.equal(a[i], b[i]), i
+        assert relerr(b[2], a[2]) < 1e-6            # the residual operand differs by nothing but is recomputed per run
+        for i in (1, 5):
+            assert torch.allclose(a[i].double().sum(0), b[i].double().sum(0), rtol=1e-5, atol=1e-3), i
+    finally:
+        ops.SPLIT, ops.WS_CONV, ops.WS_FORCE = old
+
+
 def test_bn_apply_sign_mask(ops):
     """spk_bn_apply's optional 1-bit output: bit k of word j of a pixel = (out[pixel][32 j + k] > 0)."""
     torch.manual_seed(1)
