@@ -140,8 +140,14 @@ int spk_stats_pool_fwd(const float* x /*[B][H][W][C]*/, float* out /*[B][C*H*(1+
 int spk_stats_pool_bwd(const float* x, const float* gout, float* dx, int B, int H, int W, int C, int mode, void* stream);
 
 /* ---- GEMM (fc1 = nn.Linear(5120,256) scripts/model.py:357; cosine F.linear :485; their gradients) ------ */
+/* C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C[m][n]).  64x64 tiles on the fp32 matrix
+ * instruction, K cut into spk_gemm_splitk(M,N,K) slices whose partial tiles go through `workspace`
+ * (spk_gemm_workspace(M,N,K) bytes, caller-owned) and are folded in a fixed order. */
+int spk_gemm_splitk(int M, int N, int K);
+size_t spk_gemm_workspace(int M, int N, int K);
 int spk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long long sam,
-                 long long sak, long long sbk, long long sbn, long long ldc, float alpha, int accumulate, void* stream);
+                 long long sak, long long sbk, long long sbn, long long ldc, float alpha, int accumulate, float* workspace,
+                 void* stream);
 int spk_colsum(const float* dy, float* db, int M, int N, int accumulate, void* stream);
 
 /* ---- heads ------------------------------------------------------------------------------------------- */

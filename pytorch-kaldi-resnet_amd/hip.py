@@ -41,7 +41,8 @@ _SIGS = {
     "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P],
     "spk_stats_pool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "spk_gemm_f32": [_P] * 4 + [_I] * 3 + [_L] * 5 + [_F, _I, _P],
+    "spk_gemm_f32": [_P] * 4 + [_I] * 3 + [_L] * 5 + [_F, _I, _P, _P],
+    "spk_gemm_splitk": [_I, _I, _I],
     "spk_colsum": [_P, _P, _I, _I, _I, _P],
     "spk_l2norm_fwd": [_P, _P, _P, _I, _I, _F, _P],
     "spk_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _F, _I, _P],
@@ -86,6 +87,8 @@ def lib():
         l.spk_conv_wgrad_workspace.argtypes = [_I, _I, _I, _I]
         l.spk_bn_finalize_workspace.restype = ctypes.c_size_t
         l.spk_bn_finalize_workspace.argtypes = [_I, _I]
+        l.spk_gemm_workspace.restype = ctypes.c_size_t
+        l.spk_gemm_workspace.argtypes = [_I, _I, _I]
         for name, sig in _SIGS.items():
             fn = getattr(l, name)
             fn.argtypes = sig
@@ -95,7 +98,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["spk_version", "spk_last_error", "spk_conv_wgrad_workspace", "spk_bn_finalize_workspace"] + list(_SIGS)
+    return ["spk_version", "spk_last_error", "spk_conv_wgrad_workspace", "spk_bn_finalize_workspace", "spk_gemm_workspace"] + list(_SIGS)
 
 
 def ptr(t):

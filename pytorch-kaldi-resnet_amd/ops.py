@@ -320,6 +320,18 @@ def _workspace(nbytes, device):
     return w
 
 
+def _workspace_named(name, nbytes, device):
+    """like _workspace, with its own buffer per purpose (a GEMM may run between a weight gradient and its slab reduce)"""
+    key = (name, str(device), torch.cuda.current_stream().cuda_stream)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() * 4 < nbytes:
+        if w is not None:
+            _ws_retired.append(w)
+        w = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _ws_cache[key] = w
+    return w
+
+
 def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy."""
     B, IH, IW, Cin = x.shape
@@ -476,8 +488,9 @@ def gemm(A, Bm, M, N, K, sam, sak, sbk, sbn, bias=None, out=None, alpha=1.0, acc
     """out[M][N] = alpha * sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn] (+bias[n]) (+out)."""
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    ws = _workspace_named("gemm", hip.lib().spk_gemm_workspace(M, N, K), A.device)
     call("spk_gemm_f32", ptr(A), ptr(Bm), ptr(out), ptr(bias), M, N, K, sam, sak, sbk, sbn, out.stride(0), float(alpha),
-         1 if accumulate else 0, stream(), label="gemm_f32_kernel", flops=2.0 * M * N * K)
+         1 if accumulate else 0, ptr(ws), stream(), label="gemm_f32_kernel", flops=2.0 * M * N * K)
     return out
 
 

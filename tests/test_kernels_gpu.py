@@ -216,11 +216,11 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape):
                            torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1])
         coef = torch.stack([torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.01,
                             torch.randn(C, device="cuda") * 0.01])
+        e2 = torch.rand(2, C, device="cuda") + 0.5
         res = {}
         for ws in (False, True):
             ops.WS_CONV, ops.WS_FORCE = ws, (tile if ws else None)
             out, st = ops.conv_fwd(x, wpk, C, 3, stride, in_affine=(sc, sh), stats=True)
-            e2 = torch.rand(2, C, device="cuda") + 0.5
             res_in = out * 0.5
             out2, _ = ops.conv_fwd(x, wpk, C, 3, stride, epi_affine=(e2[0], e2[1]), epi_add=res_in, relu=True)
             draw = torch.full_like(raw, 7.0)
@@ -229,9 +229,8 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape):
             dxp = ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, Wd), add=dout)
             res[ws] = (out, st, out2, dx, draw, part, dxp)
         a, b = res[False], res[True]
-        for i in (0, 3, 4, 6):
+        for i in (0, 2, 3, 4, 6):
             assert torch.equal(a[i], b[i]), i
-        assert relerr(b[2], a[2]) < 1e-6            # the residual operand differs by nothing but is recomputed per run
         for i in (1, 5):
             assert torch.allclose(a[i].double().sum(0), b[i].double().sum(0), rtol=1e-5, atol=1e-3), i
     finally:
