@@ -50,7 +50,8 @@ def mfma_peak(kernel_label):
     elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 4:
         terms = int(inner[2])
     if terms:
-        return PEAK_BF16_MFMA_TFLOPS / terms, "bf16 dense peak / %d cross products per fp32 multiply-add" % terms
+        return PEAK_BF16_MFMA_TFLOPS / terms, "%s dense peak / %d cross products per fp32 multiply-add" % (
+            "fp16" if terms == 3 else "bf16", terms)
     return PEAK_F32_MFMA_TFLOPS, "fp32 dense matrix peak"
 
 
@@ -70,7 +71,7 @@ def parse():
     ap.add_argument("--frames-range", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="one chunk length per step, uniform in [LO, HI] (seeded) like the reference's variable-length "
                          "batches (scripts/datasets.py:178-193); implies eager launches")
-    ap.add_argument("--mfma", choices=["bf16x6", "bf16x9", "f32"], default=None,
+    ap.add_argument("--mfma", choices=["f16x3", "bf16x6", "bf16x9", "f32"], default=None,
                     help="operand mode of the 3x3 convolutions (default: the package default, bf16x6 = fp32 operands as three "
                          "exact bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate; f32 = native fp32 MFMA)")
     ap.add_argument("--autotune", action="store_true", help="time candidate tiles on first use of a launch shape (SPK_AUTOTUNE=1)")
@@ -512,7 +513,9 @@ def main():
             "value": round(gb * args.steps / dt, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if ops.SPLIT == 0 else "f32 (operands as 3 exact bf16 terms, %d cross products, f32 accumulate)" % ops.SPLIT,
+            "dtype": "f32" if ops.SPLIT == 0 else (
+                "f32 (operands as 2 fp16 terms of value x 2^k, 3 cross products, f32 accumulate)" if ops.SPLIT == 3 else
+                "f32 (operands as 3 exact bf16 terms, %d cross products, f32 accumulate)" % ops.SPLIT),
             "data": "synthetic",
             "config": {"workload": "%s: %s + AAM-softmax (m 0.2, s 30), %d speakers, "
                                    "%s x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"

@@ -45,9 +45,11 @@ const char* spk_last_error(void);
 /* nn.Conv2d weight [Cout][Cin][KH][KW] (scripts/model.py:12-15,105-110,233-234) -> MFMA fragment order
  * [tap][K/8][N/32][64][4]; transpose = 0 for the forward conv (K = Cin), 1 for its data gradient (K = Cout). */
 int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
-/* the same weights for the bf16-split operand mode of spk_conv_mfma (split = 6 or 9): every weight as three bf16 terms
- * whose sum is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight */
-int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
+/* the same weights for the split operand modes of spk_conv_mfma: split = 6 or 9: every weight as three bf16 terms whose sum
+ * is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight; split = 3: w * 2^12 as two fp16 terms
+ * (saturated), the same order with two terms = 4 bytes per weight */
+int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, int split,
+                               void* stream);
 /* every convolution of the network in one launch: `jobs` is a device array of njobs 48-byte entries
  * { const float* w; void* wpk; int Cout, Cin, KH*KW, transpose, split, total = Cout*Cin*KH*KW, block0, pad; } ordered by
  * block0 (first 256-thread block of the job; total_blocks = sum of ceil(total/256)).  spk_pack_job_bytes() = 48. */
@@ -67,7 +69,13 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * split: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (wpk from spk_pack_conv_weight); 6 or 9 = operands split exactly into
  * three bf16 terms while staged / packed (wpk from spk_pack_conv_weight_split) and the 6 most significant (or all 9) cross
  * terms multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - inputs, outputs and measured accuracy are fp32
- * (planes are then 16 channels: Cin % (16*kc) == 0). */
+ * (planes are then 16 channels: Cin % (16*kc) == 0).
+ * split = 3 ("f16x3"): operands as two fp16 terms of value * sigma, sigma a power of two (weights: 2^12 at pack time;
+ * staged input: 2^6 when in_amax is NULL - activations - else 2^(8 - exponent) of the float whose bits *in_amax holds,
+ * the tensor's absmax or an upper estimate of it: gradients), three cross products on v_mfma_f32_32x32x16_f16, fp32
+ * accumulation, accumulators scaled back by 1/(sigma_in * 2^12).  Measured accuracy = the fp32 instruction's
+ * (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the launch atomically maxes the float
+ * bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume those tensors. */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
                   const float* in_act, const float* in_bn4, const float* in_coef, const unsigned* in_mask /* sign bits of
@@ -77,7 +85,8 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
                   const float* bn_raw, const float* bn_act, const float* bn4, float* stats, int B, int IH,
                   int IW, int Cin, int OH, int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox,
                   int ntaps, const int* tap_dy /*host*/, const int* tap_dx /*host*/, const int* tap_w /*host*/, int TH,
-                  int TW, int MT, int NT, int kc, int ips, int flags, int split, void* stream);
+                  int TW, int MT, int NT, int kc, int ips, int flags, int split, const unsigned* in_amax, unsigned* out_amax,
+                  unsigned* side_amax, void* stream);
 
 /* Weight gradient of a 3x3 (pad 1) or 1x1 (pad 0) conv at stride 1 or 2 (autograd of nn.Conv2d).
  * x: conv input [B][IH][IW][Cin] (optionally raw + fused BN/ReLU via in_scale/in_shift and SPK_IN_AFFINE_RELU),
@@ -91,14 +100,17 @@ size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
 int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate, void* stream);
 int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                    const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,
-                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, int split /* 0, or 6 / 9 = bf16-split operands
-                   (3x3 only), see spk_conv_mfma */, void* stream);
+                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, int split /* 0, or 6 / 9 = bf16-split operands,
+                   3 = fp16 two-term operands (3x3 only), see spk_conv_mfma */, const unsigned* dy_amax /* split 3: float bits
+                   of absmax(dy), fixes the dY operand scale */, const unsigned* x_amax /* the same for the (transformed) x
+                   operand: its absmax or an upper estimate (spk_affine_estimate) */, void* stream);
 
 /* Stem Conv2d(1,32,3,1,1,bias=False) (scripts/model.py:210,249): x [B][F][T] -> out [B][F][T][32];
  * stats (EPI_STATS): [spk_stem_fwd_blocks()][32][2]. */
 int spk_stem_fwd_blocks(int B, int F, int T);
 int spk_stem_conv_fwd(const float* x, const float* w, float* out, float* stats, const float* epi_scale,
-                      const float* epi_shift, int B, int F, int T, int flags, void* stream);
+                      const float* epi_shift, int B, int F, int T, int flags,
+                      unsigned* amax_out /* optional: atomicMax of the float bits of |out| */, void* stream);
 /* its weight gradient; partial: [spk_stem_wgrad_blocks()][32*9] floats */
 int spk_stem_wgrad_blocks(int B, int F, int T);
 int spk_stem_conv_wgrad(const float* x, const float* draw, float* dw, float* partial, int B, int F, int T,
@@ -123,7 +135,8 @@ int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * mask_out (optional, C % 32 == 0): sign bits of `out`, one uint32 per 32 channels of a pixel ([N][C/32]); the backward
  * kernels read these bits (spk_conv_mfma in_mask / bn_mask) instead of the activated tensor. */
 int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
-                 const float* res_shift, float* out, unsigned* mask_out, long long N, int C, int relu, void* stream);
+                 const float* res_shift, float* out, unsigned* mask_out, long long N, int C, int relu,
+                 unsigned* amax_out /* optional: atomicMax of the float bits of |out| */, void* stream);
 /* backward; mask_mode 0: dz = dy, 1: dz = dy*(act > 0), 2: dz = dy*(raw*scale+shift > 0) */
 int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
@@ -132,7 +145,16 @@ int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, con
                         float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws, void* stream);
 int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,
-                     int C, int mask_mode, void* stream);
+                     int C, int mask_mode, unsigned* amax_out /* optional: atomicMax of the float bits of |draw| */,
+                     void* stream);
+/* operand-scale hand-offs of the f16x3 mode (see spk_conv_mfma): *slot = max(*slot, bits(max|x|)); and the upper estimate
+ * max_c |k1_c| (A + |m1_c| + 8 |m2_c|) of the values a fused BatchNorm-backward data gradient stages, from the coefficient
+ * rows coef[3][C] of spk_bn_bwd_finalize and A = the float whose bits *amax_in holds (absmax of the incoming gradient) */
+int spk_absmax(const float* x, unsigned* slot, long long n, void* stream);
+int spk_bnbwd_estimate(const float* coef, int C, const unsigned* amax_in, unsigned* est, void* stream);
+/* upper bound of |relu(raw * scale_c + shift_c)| from A = absmax(raw): max_c |scale_c| * A + max_c |shift_c| - the operand
+ * scale input of a convolution / weight gradient that applies BatchNorm+ReLU while staging (SPK_IN_AFFINE_RELU) */
+int spk_affine_estimate(const float* scale, const float* shift, int C, const unsigned* amax_in, unsigned* est, void* stream);
 
 /* ---- statistics pooling (StatsPooling, scripts/model.py:435-457; mode 0 = 'mean', 1 = 'mean+std') -------- */
 int spk_stats_pool_fwd(const float* x /*[B][H][W][C]*/, float* out /*[B][C*H*(1+mode)]*/, int B, int H, int W, int C,

@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                        float* __restrict__ out, unsigned* __restrict__ mask_out, long long nquads,
-                                                       int C, int relu) {
+                                                       int C, int relu, unsigned* __restrict__ amax_out) {
     const int cmask = C - 1;
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
         const int c = (int)((i * 4) & cmask);
         f32x4 v = *(const f32x4*)(raw + i * 4);
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             v[3] = fmaxf(v[3], 0.f);
         }
         *(f32x4*)(out + i * 4) = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         if (mask_out) {
             // sign mask of the output, one bit per value, 32 channels per word: the backward pass reads these bits instead
             // of the whole activated tensor.  Eight consecutive lanes hold the 32 channels of one word (C % 32 == 0, the
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             if ((threadIdx.x & 7) == 0) mask_out[i >> 3] = bits;
         }
     }
+    if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(out): the operand scale of its f16x3 consumers
 }
 
 static int stream_grid(long long nquads) {
@@ -242,7 +245,7 @@ static int stream_grid(long long nquads) {
 
 extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res,
                             const float* res_scale, const float* res_shift, float* out, unsigned* mask_out, long long N, int C,
-                            int relu, void* stream) {
+                            int relu, unsigned* amax_out, void* stream) {
     SPK_REQUIRE(raw && scale && shift && out, "spk_bn_apply: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_apply: N=%lld C=%d", N, C);
     SPK_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), "spk_bn_apply: residual affine must come in pairs");
@@ -250,7 +253,7 @@ extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* s
     SPK_REQUIRE(!mask_out || C % 32 == 0, "spk_bn_apply: the sign mask needs C %% 32 == 0 (C=%d)", C);
     const long long nquads = N * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res,
-                       res_scale, res_shift, out, mask_out, nquads, C, relu);
+                       res_scale, res_shift, out, mask_out, nquads, C, relu, amax_out);
     SPK_LAUNCH_CHECK("spk_bn_apply");
     return 0;
 }
@@ -385,8 +388,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef,
                                                            float* __restrict__ draw, float* __restrict__ dz_out,
-                                                           long long nquads, int C, int mode) {
+                                                           long long nquads, int C, int mode, unsigned* __restrict__ amax_out) {
     const int cmask = C - 1;
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
         const int c = (int)((i * 4) & cmask);
         const long long off = i * 4;
@@ -398,19 +402,101 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 o = k1 * (d - m1 - xh * m2);
         if (dz_out) *(f32x4*)(dz_out + off) = d;
         *(f32x4*)(draw + off) = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
+    if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(draw): the operand scale of its f16x3 consumers
 }
 
 extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                                 const float* scale, const float* shift, const float* coef, float* draw, float* dz_out,
-                                long long N, int C, int mask_mode, void* stream) {
+                                long long N, int C, int mask_mode, unsigned* amax_out, void* stream) {
     SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && coef && draw, "spk_bn_bwd_apply: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_apply: N=%lld C=%d", N, C);
     SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
     SPK_REQUIRE(mask_mode != MASK_ACT || act, "spk_bn_bwd_apply: MASK_ACT needs the activated tensor");
     const long long nquads = N * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
-                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode);
+                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out);
     SPK_LAUNCH_CHECK("spk_bn_bwd_apply");
+    return 0;
+}
+
+// ---- operand-scale hand-offs of the f16x3 mode ---------------------------------------------------------------------
+// *slot = max(*slot, float bits of max|x|)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ slot) {
+    float mx = 0.f;
+    const long long nq = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[nq * 4 + threadIdx.x]));
+    spk_wave_amax_commit(mx, slot);
+}
+
+extern "C" int spk_absmax(const float* x, unsigned* slot, long long n, void* stream) {
+    SPK_REQUIRE(x && slot && n > 0, "spk_absmax: bad arguments");
+    SPK_REQUIRE((((size_t)x) & 15) == 0, "spk_absmax: x must be 16-byte aligned");
+    hipLaunchKernelGGL(absmax_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, n, slot);
+    SPK_LAUNCH_CHECK("spk_absmax");
+    return 0;
+}
+
+// Upper estimate of max |k1 (dz - m1 - xhat m2)| - the values a fused BatchNorm-backward data gradient stages - from the
+// coefficient rows [k1, m1, m2][C] and A = absmax of the incoming gradient (|dz| <= A): max_c |k1_c| (A + |m1_c| + 8 |m2_c|).
+// |xhat| <= 8 is a heuristic (values beyond it saturate gracefully: the staged fp16 terms are clamped), the operand scale
+// derived from the estimate leaves 2^7 of headroom on top.  *est = float bits (plain store: one estimate per launch).
+__global__ __launch_bounds__(256) void bnbwd_estimate_kernel(const float* __restrict__ coef, int C, const unsigned* __restrict__ amax_in,
+                                                             unsigned* __restrict__ est) {
+    __shared__ float red[4];
+    const float A = __uint_as_float(*amax_in);
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, fabsf(coef[c]) * (A + fabsf(coef[C + c]) + 8.f * fabsf(coef[2 * C + c])));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) *est = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// Upper bound of |max(raw * scale_c + shift_c, 0)| - what a convolution with the fused input BatchNorm+ReLU stages - from
+// A = absmax(raw): max_c |scale_c| * A + max_c |shift_c|.
+__global__ __launch_bounds__(256) void affine_estimate_kernel(const float* __restrict__ scale, const float* __restrict__ shift, int C,
+                                                              const unsigned* __restrict__ amax_in, unsigned* __restrict__ est) {
+    __shared__ float red[2][4];
+    float ms = 0.f, mh = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        ms = fmaxf(ms, fabsf(scale[c]));
+        mh = fmaxf(mh, fabsf(shift[c]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, off, 64));
+        mh = fmaxf(mh, __shfl_xor(mh, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = ms;
+        red[1][threadIdx.x >> 6] = mh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ms = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        mh = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        *est = __float_as_uint(ms * __uint_as_float(*amax_in) + mh);
+    }
+}
+
+extern "C" int spk_affine_estimate(const float* scale, const float* shift, int C, const unsigned* amax_in, unsigned* est,
+                                   void* stream) {
+    SPK_REQUIRE(scale && shift && amax_in && est && C > 0, "spk_affine_estimate: bad arguments");
+    hipLaunchKernelGGL(affine_estimate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scale, shift, C, amax_in, est);
+    SPK_LAUNCH_CHECK("spk_affine_estimate");
+    return 0;
+}
+
+extern "C" int spk_bnbwd_estimate(const float* coef, int C, const unsigned* amax_in, unsigned* est, void* stream) {
+    SPK_REQUIRE(coef && amax_in && est && C > 0, "spk_bnbwd_estimate: bad arguments");
+    hipLaunchKernelGGL(bnbwd_estimate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, coef, C, amax_in, est);
+    SPK_LAUNCH_CHECK("spk_bnbwd_estimate");
     return 0;
 }

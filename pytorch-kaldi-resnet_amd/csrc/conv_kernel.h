@@ -15,15 +15,20 @@
 // (tools/probe/split_probe.hip), at 16/6 of its rate.
 #define SPK_SPLIT_CK 16   // channels per staged plane of the bf16-split kernels (32 = full 128-byte lines per pass was
                           // measured 5 % slower: 208-byte LDS pixels force smaller tiles)
+// SPLIT == 3: fp16 two-term operands (spk_common.h, "f16x3"): same structure with two terms per value, three products on
+// v_mfma_f32_32x32x16_f16, a power-of-two input scale (static for activations, from the tensor's absmax for gradients)
+// and the accumulators scaled back in the epilogue.
 template <int SPLIT>
 struct ConvCfg {
+    static constexpr int NTERM = SPLIT == 3 ? 2 : 3;       // operand terms (split kernels)
+    static constexpr int MAXSUM = SPLIT == 9 ? 4 : (SPLIT == 6 ? 2 : 1);   // products (sa, sb) with sa + sb <= MAXSUM
     static constexpr int CK = SPLIT ? SPK_SPLIT_CK : 32;   // channels per staged plane
     static constexpr int TPP = CK / 4;           // threads per staged pixel (one float4 of channels each)
     static constexpr int PPP = 256 / TPP;        // pixels per staging pass of the block
     static constexpr int KG = CK / 16;           // split: 16-channel MFMA groups per plane
     // LDS pixel pitch in 16-byte units: fp32 [32 ch + 4 pad] = 144 B; split [3 terms][CK ch bf16] + 16 pad = 112 / 208 B.
     // All are odd multiples of 16 B, so the 8 lanes of a ds_read_b128 phase (consecutive pixels) hit distinct bank groups.
-    static constexpr int LP4 = SPLIT ? (3 * CK * 2 + 16) / 16 : 9;
+    static constexpr int LP4 = SPLIT ? (NTERM * CK * 2 + 16) / 16 : 9;
 };
 
 struct ConvArgs {
@@ -61,6 +66,11 @@ struct ConvArgs {
     int tap_off[9];   // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
     int tap_w[9];     // weight tap index
     int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
+    // f16x3 operand mode (SPLIT == 3)
+    const unsigned* in_amax;   // float bits of the staged tensor's absmax (or an upper estimate); NULL: static in_sigma
+    float in_sigma, w_sigma;   // static input scale (activations) and the weight scale the packed weights carry
+    unsigned* out_amax;        // optional: atomicMax of |stored output| (float bits) - the next consumer's in_amax
+    unsigned* side_amax;       // optional (IN_BNBWD): atomicMax of |side_draw| - the weight gradient's dY scale
     int tap_boff[9];  // wave-specialised kernel: float offset of (tap, channel plane 0) in the bf16-split packed weights
     int kc;           // channel planes (of 32) staged per barrier: > 1 only for single-tap (1x1) convolutions, whose K loop
                       // per 32-channel chunk is too short to amortise a staging phase
@@ -69,11 +79,18 @@ struct ConvArgs {
 template <int MT, int NT, bool BNBWD, int SPLIT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     using Cfg = ConvCfg<SPLIT>;
-    constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4;
+    constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // f16x3: input scale (a power of two) and the factor that takes the accumulators back to fp32 units
+    float sig = 1.f, inv_sig = 1.f;
+    if constexpr (SPLIT == 3) {
+        sig = a.in_amax ? spk_sigma_from_amax_bits(*a.in_amax) : a.in_sigma;
+        inv_sig = 1.f / (sig * a.w_sigma);       // exact: both are powers of two
+    }
+    float side_mx = 0.f;
 
     // XCD-aware remap (bijective for any grid size): blocks that are adjacent in the logical
     // order (same pixel region, next cout group; then the neighbouring region) share an XCD's L2.
@@ -125,6 +142,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     auto store_px = [&](float* plane, int p, f32x4 w) {
         if constexpr (SPLIT == 0) {
             *(f32x4*)(plane + p * (LP4 * 4) + quad * 4) = w;
+        } else if constexpr (SPLIT == 3) {
+            uint2 t0, t1;
+            split2h(w, sig, t0, t1);
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][CK ch]: CK*2 bytes per term
+            dst[0] = t0;
+            dst[CK / 4] = t1;
         } else {
             uint2 t0, t1, t2;
             split3(w, t0, t1, t2);
@@ -198,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                             if (owner && core[u]) {
                                 *(f32x4*)(a.side_draw + off[u]) = w;
                                 if (a.side_dz) *(f32x4*)(a.side_dz + off[u]) = dz;
+                                side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                             }
                         }
                     }
@@ -335,9 +359,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             // per n-tile, SPLIT MFMAs per (m-tile, n-tile).
             const f32x4* lds4 = (const f32x4*)lds;
             // packed weights: [tap][Cin/16][term][Cout/32][64 lanes][8 bf16]
-            const float* wbase = a.wpk + ((size_t)(ch * a.kc) * 3 * cout32 + cg * NT) * 256 + lane * 4;
-            const size_t tap_stride = (size_t)(a.Cin >> 4) * 3 * cout32 * 256;
-            const size_t grp_stride = (size_t)3 * cout32 * 256;
+            const float* wbase = a.wpk + ((size_t)(ch * a.kc) * NTERM * cout32 + cg * NT) * 256 + lane * 4;
+            const size_t tap_stride = (size_t)(a.Cin >> 4) * NTERM * cout32 * 256;
+            const size_t grp_stride = (size_t)NTERM * cout32 * 256;
             const size_t term_stride = (size_t)cout32 * 256;
             auto load_b = [&](f32x4 (*bf)[NT], int tw, int g) {
 #ifdef ABL_B_SAMEADDR
@@ -346,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const float* wp = wbase + (size_t)tw * tap_stride + (size_t)g * grp_stride;
 #endif
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NTERM; ++s)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
 #ifdef ABL_NO_BLOAD
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             };
             auto load_a = [&](f32x4 (*af)[MT], int toff4, int g) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NTERM; ++s)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
 #ifdef ABL_NO_ALOAD
@@ -374,9 +398,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 // ahead (three register buffers in rotation), while the A fragments (LDS, ~100 cycles) roll inside one
                 // buffer: as soon as the MFMAs of m-tile i have issued, the next step's fragments of that m-tile are read
                 // into the same registers.  Tap-table entries (scalar loads) are fetched three steps early.
-                f32x4 b0[3][NT], b1[3][NT], b2[3][NT], aq[3][MT];
+                f32x4 b0[NTERM][NT], b1[NTERM][NT], b2[NTERM][NT], aq[NTERM][MT];
 #if defined(ABL_NO_BLOAD) || defined(ABL_NO_ALOAD)
-                for (int s = 0; s < 3; ++s) {
+                for (int s = 0; s < NTERM; ++s) {
                     for (int j = 0; j < NT; ++j) b0[s][j] = b1[s][j] = b2[s][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
                     for (int i = 0; i < MT; ++i) aq[s][i] = (f32x4){1.f, 2.f, 3.f, 4.f};
                 }
@@ -388,20 +412,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     for (int i = 0; i < MT; ++i) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+                        for (int sum = Cfg::MAXSUM; sum >= 0; --sum)
 #pragma unroll
-                            for (int sa = 0; sa < 3; ++sa) {
+                            for (int sa = 0; sa < NTERM; ++sa) {
                                 const int sb = sum - sa;
-                                if (sb < 0 || sb > 2) continue;
+                                if (sb < 0 || sb >= NTERM) continue;
 #pragma unroll
-                                for (int j = 0; j < NT; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[sa][i]),
-                                                                                       __builtin_bit_cast(bf16x8, bc[sb][j]),
-                                                                                       acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < NT; ++j) {
+                                    if constexpr (SPLIT == 3)
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[sa][i]),
+                                                                                          __builtin_bit_cast(f16x8, bc[sb][j]),
+                                                                                          acc[i][j], 0, 0, 0);
+                                    else
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[sa][i]),
+                                                                                           __builtin_bit_cast(bf16x8, bc[sb][j]),
+                                                                                           acc[i][j], 0, 0, 0);
+                                }
                             }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) {
+                        for (int s = 0; s < NTERM; ++s) {
 #ifdef ABL_NO_ALOAD
                             asm volatile("" : "+v"(aq[s][i]) : "s"(o_next));
 #else
@@ -464,6 +494,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         bsh = *(const f32x4*)(a.bn4 + 3 * a.Cout + n0 + qc * 4);
     }
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    float out_mx = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -471,7 +502,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[row * LW + j * 32 + r] = acc[i][j][e];
+                slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig : acc[i][j][e];
             }
         // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
 #pragma unroll
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     v[3] = fmaxf(v[3], 0.f);
                 }
                 *(f32x4*)dst = v;
+                out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (flags & SPK_EPI_BNBWD) {
                     // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
                     // its backward needs no separate reduction pass over this tensor
@@ -529,6 +561,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
         }
+    }
+    // absmax of what this launch stored (the scale of the next f16x3 consumer of the tensor): one atomicMax per wave
+    if (a.out_amax) spk_wave_amax_commit(out_mx, a.out_amax);
+    if constexpr (BNBWD) {
+        if (a.side_amax) spk_wave_amax_commit(side_mx, a.side_amax);
     }
     if (flags & SPK_EPI_STATS) {
         // lanes with equal qc hold the same 4 channels: fold them (lane strides Q, 2Q, ... < 64)

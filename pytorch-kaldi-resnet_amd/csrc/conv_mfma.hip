@@ -46,7 +46,8 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
                              const float* bn_act, const float* bn4, float* stats, int B, int IH, int IW, int Cin, int OH,
                              int OW, int OHf, int OWf, int Cout, int IS, int OS, int ooy, int oox, int ntaps,
                              const int* tap_dy, const int* tap_dx, const int* tap_w, int TH, int TW, int MT,
-                             int NT, int kc, int ips, int flags, int split, void* stream) {
+                             int NT, int kc, int ips, int flags, int split, const unsigned* in_amax, unsigned* out_amax,
+                             unsigned* side_amax, void* stream) {
     SPK_REQUIRE(in && wpk && out, "spk_conv_mfma: null pointer");
     SPK_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "spk_conv_mfma: empty tensor");
     SPK_REQUIRE(Cin % 32 == 0 && Cin > 0, "spk_conv_mfma: Cin=%d must be a multiple of 32", Cin);
@@ -55,9 +56,11 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(ws_wc <= 4, "spk_conv_mfma: bad wave layout");
     SPK_REQUIRE(NT >= 1 && Cout % (32 * NT * ws_wc) == 0, "spk_conv_mfma: Cout=%d not a multiple of 32*NT*WC (NT=%d, WC=%d)", Cout, NT, ws_wc);
     SPK_REQUIRE(ntaps >= 1 && ntaps <= 9, "spk_conv_mfma: ntaps=%d out of range", ntaps);
-    SPK_REQUIRE(split == 0 || split == 6 || split == 9, "spk_conv_mfma: split=%d (0 = fp32 operands, 6 / 9 = bf16 cross terms)", split);
+    SPK_REQUIRE(split == 0 || split == 3 || split == 6 || split == 9,
+                "spk_conv_mfma: split=%d (0 = fp32 operands, 6 / 9 = bf16 cross terms, 3 = fp16 two-term operands)", split);
     const int ck = split ? SPK_SPLIT_CK : 32;                     // channels per staged plane
-    const int lp4 = split ? (3 * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
+    const int nterm = split == 3 ? 2 : 3;
+    const int lp4 = split ? (nterm * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
     SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
     SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT / ws_wc, "spk_conv_mfma: tile %dx%d exceeds %d pixels (MT=%d)", TH, TW, 128 * MT / ws_wc, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
@@ -80,6 +83,9 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.bn_raw = bn_raw; a.bn_act = bn_act; a.bn4 = bn4;
     a.in_raw = in_raw; a.in_act = in_act; a.in_bn4 = in_bn4; a.in_coef = in_coef; a.side_draw = side_draw; a.side_dz = side_dz;
     a.in_mask = in_mask; a.bn_mask = bn_mask; a.add_mask = add_mask;
+    a.in_amax = in_amax; a.out_amax = out_amax; a.side_amax = side_amax;
+    a.in_sigma = SPK_F16_ACT_SIGMA; a.w_sigma = SPK_F16_W_SIGMA;
+    SPK_REQUIRE(!(flags & SPK_CONV_WS) || split != 3, "spk_conv_mfma: the wave-specialised kernel has no f16x3 instantiation");
     SPK_REQUIRE(!add_mask || ((flags & SPK_EPI_ADD) && Cout % 32 == 0), "spk_conv_mfma: add_mask needs EPI_ADD and Cout %% 32 == 0");
     SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);
     a.B = B; a.IHp = IH; a.IWp = IW; a.ips = ips; a.IH = (IH + ips - 1) / ips; a.IW = (IW + ips - 1) / ips; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;

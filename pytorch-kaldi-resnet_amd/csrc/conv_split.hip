@@ -1,6 +1,7 @@
 // bf16-split instantiations of the implicit-GEMM convolution (see conv_kernel.h, ConvCfg<SPLIT>) (the matching weight
 // packing is in pack.hip).  fp32 activations and weights go in, fp32 results come out; inside, every operand is the exact sum of three
-// bf16 terms and the matrix cores multiply the 6 most significant cross terms (or all 9) with fp32 accumulation.
+// bf16 terms and the matrix cores multiply the 6 most significant cross terms (or all 9) with fp32 accumulation; split == 3
+// is the fp16 two-term form (three products on v_mfma_f32_32x32x16_f16, power-of-two operand scales).
 #include "conv_kernel.h"
 
 template <int MT, int NT, int SPLIT>
@@ -16,6 +17,7 @@ static int launch_split(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
 int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, int split, hipStream_t st) {
 #define CASE(M, N)                                                      \
     if (MT == M && NT == N) {                                           \
+        if (split == 3) return launch_split<M, N, 3>(a, lds_bytes, st); \
         if (split == 6) return launch_split<M, N, 6>(a, lds_bytes, st); \
         return launch_split<M, N, 9>(a, lds_bytes, st);                 \
     }

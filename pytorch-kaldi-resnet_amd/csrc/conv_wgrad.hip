@@ -269,7 +269,7 @@ extern "C" int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int 
 extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                               const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout,
                               int ksize, int stride, int TH, int TW, int WN, int nsplit, int flags, int accumulate,
-                              int split, void* stream) {
+                              int split, const unsigned* dy_amax, const unsigned* x_amax, void* stream) {
     SPK_REQUIRE(x && dy && dw && partial, "spk_conv_wgrad: null pointer");
     SPK_REQUIRE(ksize == 1 || ksize == 3, "spk_conv_wgrad: ksize=%d unsupported", ksize);
     SPK_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "spk_conv_wgrad: channels (%d,%d) must be multiples of 32", Cin, Cout);
@@ -292,7 +292,8 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.halo_w_magic = (unsigned)((0x100000000ULL + (unsigned long long)a.halo_w - 1) / (unsigned long long)a.halo_w);
     a.tw_magic = (unsigned)((0x100000000ULL + (unsigned long long)TW - 1) / (unsigned long long)TW);
     a.flags = flags;
-    SPK_REQUIRE(split == 0 || ((split == 6 || split == 9) && ksize == 3), "spk_conv_wgrad: split=%d (0, or 6 / 9 for 3x3)", split);
+    a.dy_amax = dy_amax; a.x_amax = x_amax;
+    SPK_REQUIRE(split == 0 || ((split == 3 || split == 6 || split == 9) && ksize == 3), "spk_conv_wgrad: split=%d (0, or 3 / 6 / 9 for 3x3)", split);
     SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",
                 a.halo_h, a.halo_w, 32 * WGRAD_NX);
     SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",

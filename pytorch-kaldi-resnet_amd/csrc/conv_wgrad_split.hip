@@ -1,7 +1,9 @@
 // Weight gradient of the 3x3 convolutions with bf16-split operands (see conv_wgrad.hip for the fp32-operand kernel and
 // conv_kernel.h for the splitting idea): fp32 X and dY go in, fp32 dW comes out; each operand value is staged into LDS as
 // three bf16 terms whose sum is the fp32 value and the 6 most significant (or all 9) cross terms are multiplied on
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  SPLIT == 3: the fp16 two-term form (spk_common.h): X scaled by the
+// static activation scale, dY by the power of two that its absmax hand-off fixes, three products on
+// v_mfma_f32_32x32x16_f16, the slabs scaled back; the LDS images keep the three-term pitch (the third plane stays unused).
 //
 // GEMM view per tap: D[ci][co] += sum_k X[pixel k shifted by the tap][ci] * dY[pixel k][co], k = 16 output pixels per
 // MFMA.  Both operands are K-strided in memory ([pixel][channel]), so the LDS images stay [pixel][term][32 channels]
@@ -40,6 +42,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     unsigned char* xs = ldsb;
     unsigned char* dys = ldsb + halo_pix * PX;
     const int flags = a.flags;
+    constexpr int NTERM = SPLIT == 3 ? 2 : 3;
+    float sig_x = 1.f, sig_d = 1.f;
+    if constexpr (SPLIT == 3) {
+        sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
+        if (a.dy_amax) sig_d = spk_sigma_from_amax_bits(*a.dy_amax);
+    }
 
     f32x16 acc[NTAPS];
 #pragma unroll
@@ -110,12 +118,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
             }
             if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p < halo_pix) {
-                uint2 t0, t1, t2;
-                split3(w, t0, t1, t2);
                 uint2* dst = (uint2*)(xs + p * PX) + quad;
-                dst[0] = t0;
-                dst[8] = t1;
-                dst[16] = t2;
+                if constexpr (SPLIT == 3) {
+                    uint2 t0, t1;
+                    split2h(w, sig_x, t0, t1);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                } else {
+                    uint2 t0, t1, t2;
+                    split3(w, t0, t1, t2);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                    dst[16] = t2;
+                }
             }
         }
 #pragma unroll
@@ -123,12 +138,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
             const int p = tid / QPP + PSTEP * u;
             const f32x4 w = ((ind >> u) & 1) ? pd[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p < npix_pad) {
-                uint2 t0, t1, t2;
-                split3(w, t0, t1, t2);
                 uint2* dst = (uint2*)(dys + p * PD + (cq >> 3) * 192) + (cq & 7);
-                dst[0] = t0;
-                dst[8] = t1;
-                dst[16] = t2;
+                if constexpr (SPLIT == 3) {
+                    uint2 t0, t1;
+                    split2h(w, sig_d, t0, t1);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                } else {
+                    uint2 t0, t1, t2;
+                    split3(w, t0, t1, t2);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                    dst[16] = t2;
+                }
             }
         }
     };
@@ -140,13 +162,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
 
     auto mma = [&](f32x16& c, const s16x8* af, const s16x8* bf) {
 #pragma unroll
-        for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+        for (int sum = (SPLIT == 9 ? 4 : (SPLIT == 6 ? 2 : 1)); sum >= 0; --sum)
 #pragma unroll
-            for (int sa = 0; sa < 3; ++sa) {
+            for (int sa = 0; sa < NTERM; ++sa) {
                 const int sb = sum - sa;
-                if (sb < 0 || sb > 2) continue;
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[sa]), __builtin_bit_cast(bf16x8, bf[sb]), c,
-                                                            0, 0, 0);
+                if (sb < 0 || sb >= NTERM) continue;
+                if constexpr (SPLIT == 3)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[sa]), __builtin_bit_cast(f16x8, bf[sb]), c,
+                                                               0, 0, 0);
+                else
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[sa]), __builtin_bit_cast(bf16x8, bf[sb]), c,
+                                                                0, 0, 0);
             }
     };
 
@@ -169,14 +195,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
                 xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + col_off;
                 da[blk] = pix * PD + wn * 192 + col_off;
             }
-            s16x8 bf[3];
+            s16x8 bf[NTERM];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) bf[s] = tr_read8(dys + da[0] + s * 64, dys + da[1] + s * 64);
-            s16x8 a0[3], a1[3];
+            for (int s = 0; s < NTERM; ++s) bf[s] = tr_read8(dys + da[0] + s * 64, dys + da[1] + s * 64);
+            s16x8 a0[NTERM], a1[NTERM];
             auto load_a = [&](s16x8* af, int t) {
                 const int toff = ((t / 3) * a.halo_w + (t % 3)) * PX;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) af[s] = tr_read8(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+                for (int s = 0; s < NTERM; ++s) af[s] = tr_read8(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
             };
             load_a(a0, 0);
 #pragma unroll
@@ -217,12 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     }
     if (wk == 0) {
         float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
+        const float inv = SPLIT == 3 ? 1.f / (sig_x * sig_d) : 1.f;     // powers of two: exact
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = acc[t][e];
+                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = SPLIT == 3 ? acc[t][e] * inv : acc[t][e];
             }
     }
 }
@@ -237,7 +264,10 @@ static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(split): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
     const bool small = a.halo_h * a.halo_w <= 32 * 4;
-    if (split == 6) {
+    if (split == 3) {
+        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 3, 4>), grid, dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 3, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+    } else if (split == 6) {
         if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, 4>), grid, dim3(256), lds_bytes, st, a);
         else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
     } else {

@@ -3,6 +3,7 @@
 //   fp32 operands : [tap][K/8][N/32][64 lanes][4 floats]      lane l: n = 32 nt + (l & 31), k = 8 g + 4 (l >> 5) + {0..3}
 //   bf16 split    : [tap][K/16][term 0..2][N/32][64 lanes][8 bf16]  lane l: n as above, k = 16 g + 8 (l >> 5) + {0..7};
 //                   term s of a weight is the s-th bf16 of its exact three-term split (w = t0 + t1 + t2)
+//   fp16 split    : the same order with two terms: w * SPK_F16_W_SIGMA = h0 + h1 (+ 2^-22 relative), saturated (split = 3)
 // spk_pack_conv_weights_batched packs every convolution of the network in ONE launch from a device-resident job table
 // (the weights change every step, so this runs once per step: 70 tiny launches become one).
 #include "spk_common.h"
@@ -22,6 +23,7 @@ static __device__ __forceinline__ void pack_f32_elem(const float* __restrict__ w
     wpk[idx] = w[((size_t)co * Cin + ci) * KHW + t];
 }
 
+template <int NTERM>
 static __device__ __forceinline__ void pack_split_elem(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout,
                                                        int Cin, int KHW, int transpose, int idx) {
     const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
@@ -36,12 +38,22 @@ static __device__ __forceinline__ void pack_split_elem(const float* __restrict__
     const int co = transpose ? k : n, ci = transpose ? n : k;
     float x = w[((size_t)co * Cin + ci) * KHW + t];
     const size_t term = (size_t)(N >> 5) * 512;
-    const size_t o = ((((size_t)t * (K >> 4) + g) * 3) * (N >> 5) + nt) * 512 + lane * 8 + e;
+    const size_t o = ((((size_t)t * (K >> 4) + g) * NTERM) * (N >> 5) + nt) * 512 + lane * 8 + e;
+    if constexpr (NTERM == 2) {
+        x = fminf(fmaxf(x * SPK_F16_W_SIGMA, -65504.f), 65504.f);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const __bf16 b = (__bf16)x;
-        wpk[o + s * term] = __builtin_bit_cast(unsigned short, b);
-        x -= (float)b;
+        for (int s = 0; s < 2; ++s) {
+            const _Float16 b = (_Float16)x;
+            wpk[o + s * term] = __builtin_bit_cast(unsigned short, b);
+            x -= (float)b;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const __bf16 b = (__bf16)x;
+            wpk[o + s * term] = __builtin_bit_cast(unsigned short, b);
+            x -= (float)b;
+        }
     }
 }
 
@@ -52,9 +64,11 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
-                                              int KHW, int transpose, int total) {
+                                              int KHW, int transpose, int total, int split) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < total) pack_split_elem(w, wpk, Cout, Cin, KHW, transpose, idx);
+    if (idx >= total) return;
+    if (split == 3) pack_split_elem<2>(w, wpk, Cout, Cin, KHW, transpose, idx);
+    else pack_split_elem<3>(w, wpk, Cout, Cin, KHW, transpose, idx);
 }
 
 extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose,
@@ -69,14 +83,15 @@ extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Ci
     return 0;
 }
 
+// split: 6 / 9 -> three bf16 terms (numel * 6 bytes), 3 -> two fp16 terms (numel * 4 bytes)
 extern "C" int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose,
-                                          void* stream) {
+                                          int split, void* stream) {
     SPK_REQUIRE(w && wpk, "spk_pack_conv_weight_split: null pointer");
     SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight_split: channels (%d,%d) must be multiples of 32", Cout, Cin);
     SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight_split: kernel %dx%d unsupported", KH, KW);
     const int total = Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned short*)wpk, Cout, Cin, KH * KW, transpose, total);
+                       (unsigned short*)wpk, Cout, Cin, KH * KW, transpose, total, split);
     SPK_LAUNCH_CHECK("spk_pack_conv_weight_split");
     return 0;
 }
@@ -87,7 +102,7 @@ struct PackJob {
     const float* w;     // OIHW weights
     void* wpk;          // destination
     int Cout, Cin, KHW, transpose;
-    int split;          // 0 = fp32 fragment order, otherwise the three-term bf16 order
+    int split;          // 0 = fp32 fragment order, 6 / 9 = the three-term bf16 order, 3 = the two-term fp16 order
     int total;          // Cout*Cin*KHW elements = threads of this job
     int block0;         // first block of this job (jobs are ordered; block0 of job i+1 = block0 + ceil(total/256))
     int pad;
@@ -104,7 +119,8 @@ __global__ void pack_conv_weights_batched_kernel(const PackJob* __restrict__ job
     const PackJob j = jobs[lo];
     const int idx = (b - j.block0) * 256 + threadIdx.x;
     if (idx >= j.total) return;
-    if (j.split) pack_split_elem(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
+    if (j.split == 3) pack_split_elem<2>(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
+    else if (j.split) pack_split_elem<3>(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
     else pack_f32_elem(j.w, (float*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
 }
 

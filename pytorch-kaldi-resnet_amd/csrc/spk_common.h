@@ -57,5 +57,50 @@ static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uin
     t2.x = pack_bf16x2(q0, q1, r0, r1);
     t2.y = pack_bf16x2(q2, q3, r2, r3);
 }
+// ---- fp16 operand splitting ("f16x3" mode): u = v * sigma (sigma a power of two chosen so that the tensor's largest
+// magnitude lands near 2^9) is the sum of two fp16 terms up to 2^-22 |u| (2 x 11 significand bits); a product is formed
+// from the three cross terms h1*g1 + h1*g2 + h2*g1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped h2*g2 is
+// 2^-22 relative) and the accumulator is scaled back by 1 / (sigma_a * sigma_b).  Measured against fp64
+// (tools/probe/split_probe.hip, profiles/r02_split_probe.log): the same error as the native fp32 matrix instruction and
+// the 6-term bf16 split - the fp32 accumulation dominates - at half the matrix instructions of the latter.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SPK_F16_ACT_SIGMA 64.0f       // forward activations (post-BatchNorm / post-ReLU values, O(1)): static 2^6
+#define SPK_F16_W_SIGMA 4096.0f       // convolution weights (|w| < 16): static 2^12
+static __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi, float& rlo, float& rhi) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;   // round to nearest even
+    rlo = lo - (float)a;                                  // exact in fp32
+    rhi = hi - (float)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// w * sigma (saturated to the fp16 range) -> two fp16 quads (8 bytes each)
+static __device__ __forceinline__ void split2h(f32x4 w, float sigma, uint2& t0, uint2& t1) {
+    float u0 = fminf(fmaxf(w[0] * sigma, -65504.f), 65504.f), u1 = fminf(fmaxf(w[1] * sigma, -65504.f), 65504.f);
+    float u2 = fminf(fmaxf(w[2] * sigma, -65504.f), 65504.f), u3 = fminf(fmaxf(w[3] * sigma, -65504.f), 65504.f);
+    float r0, r1, r2, r3, q0, q1, q2, q3;
+    t0.x = pack_f16x2(u0, u1, r0, r1);
+    t0.y = pack_f16x2(u2, u3, r2, r3);
+    t1.x = pack_f16x2(r0, r1, q0, q1);
+    t1.y = pack_f16x2(r2, r3, q2, q3);
+}
+// power-of-two scale from the bits of a tensor's absmax (or of an upper estimate of it): amax * sigma in [2^8, 2^9)
+static __device__ __forceinline__ float spk_sigma_from_amax_bits(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xffu);            // biased exponent; amax = m * 2^(e - 127), m in [1, 2)
+    if (e == 0 || e == 255) return 1.f;                   // zero / subnormal / inf / nan: no scaling
+    int se = 127 + 8 - (e - 127);                         // sigma = 2^(8 - (e - 127))
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+// wave-wide max of a non-negative float, then one atomicMax on its bit pattern (order-independent: deterministic)
+static __device__ __forceinline__ void spk_wave_amax_commit(float v, unsigned* dst) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    // atomics on one address serialise at the memory side (~50-100 ns each): a launch with 10^5 waves would spend
+    // milliseconds there.  The slot only grows, so a wave first looks at it (device-scope load: may lag, never leads) and
+    // skips the atomic when its own maximum cannot raise it - after the first few waves almost all of them skip.
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(v);
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
+}
 #endif
 

@@ -11,8 +11,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ out, float* __restrict__ stats,
                                                        const float* __restrict__ epi_scale,
                                                        const float* __restrict__ epi_shift, int B, int F, int T,
-                                                       int flags) {
+                                                       int flags, unsigned* __restrict__ amax_out) {
     __shared__ float red[4][STEM_C][2];
+    float mx = 0.f;
     const int tid = threadIdx.x, cg = tid & 3, pl = tid >> 2;
     float wr[9][8];
 #pragma unroll
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             if (flags & SPK_EPI_AFFINE) v = v * es[c] + eh[c];
             if (flags & SPK_EPI_RELU) v = fmaxf(v, 0.f);
             o[c] = v;
+            mx = fmaxf(mx, fabsf(v));
             ssum[c] += v;
             ssq[c] += v * v;
         }
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
         dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
     }
+    if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(out): the operand scale of its f16x3 consumers
     if (flags & SPK_EPI_STATS) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -96,13 +99,13 @@ extern "C" int spk_stem_fwd_blocks(int B, int F, int T) {
 }
 
 extern "C" int spk_stem_conv_fwd(const float* x, const float* w, float* out, float* stats, const float* epi_scale,
-                                 const float* epi_shift, int B, int F, int T, int flags, void* stream) {
+                                 const float* epi_shift, int B, int F, int T, int flags, unsigned* amax_out, void* stream) {
     SPK_REQUIRE(x && w && out, "spk_stem_conv_fwd: null pointer");
     SPK_REQUIRE(B > 0 && F > 0 && T > 0, "spk_stem_conv_fwd: empty input");
     SPK_REQUIRE(!(flags & SPK_EPI_STATS) || stats, "spk_stem_conv_fwd: EPI_STATS needs a stats buffer");
     SPK_REQUIRE(!(flags & SPK_EPI_AFFINE) || (epi_scale && epi_shift), "spk_stem_conv_fwd: EPI_AFFINE needs scale/shift");
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(spk_stem_fwd_blocks(B, F, T)), dim3(256), 0, (hipStream_t)stream, x, w, out,
-                       stats, epi_scale, epi_shift, B, F, T, flags);
+                       stats, epi_scale, epi_shift, B, F, T, flags, amax_out);
     SPK_LAUNCH_CHECK("spk_stem_conv_fwd");
     return 0;
 }

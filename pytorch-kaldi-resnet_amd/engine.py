@@ -39,8 +39,9 @@ class _Conv:
             self.wpk = torch.empty(n, device=w.device, dtype=torch.float32)
         jobs = [(w, self.wpk, False)]
         if need_t:
-            if self.wpk_t is None or self.wpk_t.numel() != n:
-                self.wpk_t = torch.empty(n, device=w.device, dtype=torch.float32)
+            nt = ops.packed_numel(w, bwd=True)
+            if self.wpk_t is None or self.wpk_t.numel() != nt:
+                self.wpk_t = torch.empty(nt, device=w.device, dtype=torch.float32)
             jobs.append((w, self.wpk_t, True))
         return jobs
 
@@ -112,6 +113,8 @@ class Engine:
         self.dirty = True
         self._packed_for_bwd = False
         self._pack_tables = {}
+        self._amax_pool = None
+        self._amax_fwd = None
         # weight gradients (compute-bound, off the critical path) run on a side stream so that they overlap the
         # HBM-bound BatchNorm-backward passes of the main dgrad chain
         self.wgrad_stream = None
@@ -140,7 +143,7 @@ class Engine:
         # one launch packs every convolution (forward order, plus the transposed order the backward needs); the job
         # table lives on the device and is rebuilt only when a buffer, the operand mode or need_t changes
         jobs = [j for c in self._all_convs() for j in c.pack_jobs(need_t)]
-        key = [(w.data_ptr(), p.data_ptr(), t, ops.split_for(w.shape[2])) for w, p, t in jobs]
+        key = [(w.data_ptr(), p.data_ptr(), t, ops.split_for(w.shape[2], t)) for w, p, t in jobs]
         tab = self._pack_tables.get(need_t)
         if tab is None or tab.key != key:
             assert not torch.cuda.is_current_stream_capturing() or tab is None, "pack table changed during graph capture"
@@ -160,10 +163,24 @@ class Engine:
         return x.contiguous()
 
     # ---- inference trunk (eval-mode BN folded into conv epilogues) -----------------------------------------
+    def _fwd_pool(self, device):
+        """absmax slot table of the forward pass (f16x3 operand mode): reset at the start of every forward; the slots of
+        the convolution inputs live on in the saved records for the weight gradients."""
+        if ops.split_for(3) != 3 and ops.split_for(3, True) != 3:
+            return None
+        if self._amax_fwd is None:
+            self._amax_fwd = ops.AmaxPool(device)
+        self._amax_fwd.reset()
+        return self._amax_fwd
+
     def trunk_eval(self, x):
         self._repack(False)
+        pool = self._fwd_pool(x.device)
+        take = (lambda: pool.take()) if pool is not None else (lambda: None)
+        f16 = ops.split_for(3) == 3
         e = self.stem_bn.eval_coeffs()
-        a, _ = ops.stem_fwd(x, self.stem_conv.h.weight.data, epi_affine=(e[0], e[1]), relu=True)
+        a_amax = take()
+        a, _ = ops.stem_fwd(x, self.stem_conv.h.weight.data, epi_affine=(e[0], e[1]), relu=True, amax_out=a_amax)
         for b in self.blocks:
             evs = [bn.eval_coeffs() for bn in b.bns]
             if b.ds is not None:
@@ -171,13 +188,16 @@ class Engine:
                 res, _ = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, epi_affine=(ed[0], ed[1]))
             else:
                 res = a
-            h = a
+            h, h_amax = a, a_amax
             n = len(b.convs)
             for i, (c, ev) in enumerate(zip(b.convs, evs)):
                 last = i == n - 1
+                o_amax = take()
                 h, _ = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, epi_affine=(ev[0], ev[1]),
-                                    epi_add=res if last else None, relu=True)
-            a = h
+                                    epi_add=res if last else None, relu=True,
+                                    in_amax=h_amax if (f16 and c.k == 3) else None, out_amax=o_amax)
+                h_amax = o_amax
+            a, a_amax = h, h_amax
         return a
 
     def embed_eval(self, x):
@@ -246,36 +266,50 @@ class Engine:
     # ---- training forward -----------------------------------------------------------------------------------
     def _trunk_train(self, x, save):
         saved = {"x": x, "blocks": []}
+        pool = self._fwd_pool(x.device)
+        take = (lambda: pool.take()) if pool is not None else (lambda: None)
+        f16 = ops.split_for(3) == 3
         raw0, st = ops.stem_fwd(x, self.stem_conv.h.weight.data, stats=True)
         B, F, T, _ = raw0.shape
         t4 = self.stem_bn.finalize(st, B * F * T)
         use_masks = save and self.use_sign_masks
-        a = ops.bn_apply(raw0, t4[2], t4[3], relu=True, mask=use_masks)
+        a_amax = take()
+        a = ops.bn_apply(raw0, t4[2], t4[3], relu=True, mask=use_masks, amax_out=a_amax)
         a, amask = a if use_masks else (a, None)
         saved["raw0"] = raw0
         for b in self.blocks:
-            rec = {"x": a, "xmask": amask}
+            # in_amax[i]: slot with the absmax (or its upper estimate) of the values conv_i STAGES - the block input itself,
+            # or relu(bn(raw_{i-1})) recomputed in the staging - shared by the forward conv and its weight gradient
+            rec = {"x": a, "xmask": amask, "in_amax": []}
             raws = []
-            h, aff = a, None
+            h, aff, h_amax = a, None, a_amax
             for c, bn in zip(b.convs, b.bns):
-                raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True)
+                in_slot = h_amax
+                if aff is not None and pool is not None:
+                    in_slot = ops.affine_estimate(aff[0], aff[1], h_amax, take())
+                rec["in_amax"].append(in_slot)
+                raw_amax = take()
+                raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True,
+                                       in_amax=in_slot if (f16 and c.k == 3) else None, out_amax=raw_amax)
                 t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2])
                 raws.append(raw)
-                h, aff = raw, (t4[2], t4[3])
+                h, aff, h_amax = raw, (t4[2], t4[3]), raw_amax
+            out_amax = take()
             if b.ds is not None:
                 rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True)
                 td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2])
-                out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True, mask=use_masks)
+                out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True, mask=use_masks,
+                                   amax_out=out_amax)
                 rec["rawd"] = rawd
             else:
-                out = ops.bn_apply(h, aff[0], aff[1], res=a, relu=True, mask=use_masks)
+                out = ops.bn_apply(h, aff[0], aff[1], res=a, relu=True, mask=use_masks, amax_out=out_amax)
             out, amask = out if use_masks else (out, None)
             rec["raws"] = raws
             rec["out"] = out
             rec["mask"] = amask
             if save:
                 saved["blocks"].append(rec)
-            a = out
+            a, a_amax = out, out_amax
         return a, saved
 
     def _embed_train(self, x, save):
@@ -308,9 +342,10 @@ class Engine:
             return logits
 
     # ---- side-stream weight gradients ----------------------------------------------------------------------------
-    def _wgrad(self, x, dy, dw, k, stride, in_affine=None, accumulate=False):
+    def _wgrad(self, x, dy, dw, k, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None):
         if not self.use_side_stream:
-            return ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate)
+            return ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax,
+                                  x_amax=x_amax)
         if self.wgrad_stream is None:
             self.wgrad_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -321,7 +356,7 @@ class Engine:
                 t.record_stream(side)               # keep the allocator from recycling them under the side kernel
         # (inside a graph capture the private pool keeps every tensor of the captured region alive)
         with torch.cuda.stream(side):
-            ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate)
+            ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax, x_amax=x_amax)
 
     def _join_wgrad(self):
         if self.use_side_stream and self.wgrad_stream is not None:
@@ -339,6 +374,16 @@ class Engine:
             dpooled = ops.linear_bwd(saved["pooled"], m.fc1.weight.data, demb, m.fc1.weight.grad, m.fc1.bias.grad,
                                      accumulate=acc)
             d = ops.stats_pool_bwd(saved["feat"], dpooled, self.pool_mode)
+            # f16x3 operand mode of the backward kernels: every gradient tensor that feeds a matrix-core stage travels with
+            # a slot holding the float bits of its absmax (atomicMax'ed by the kernel that writes it); the consumer derives
+            # its power-of-two operand scale from it.  Slots are taken in a fixed order from a table zeroed once per step.
+            amx = None
+            if ops.split_for(3, True) == 3:
+                if self._amax_pool is None:
+                    self._amax_pool = ops.AmaxPool(d.device)
+                amx = self._amax_pool
+                amx.reset()
+            d_amax = ops.absmax_into(d, amx.take()) if amx else None
             if on_stage_done:
                 on_stage_done("head")
             nblk = len(self.blocks)
@@ -353,7 +398,7 @@ class Engine:
                     prev = (saved["blocks"][bi - 1]["raws"][-1], self.blocks[bi - 1].bns[-1].t4)
                 else:
                     prev = (saved["raw0"], self.stem_bn.t4)
-                d, part = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc, part, prev)
+                d, part, d_amax = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc, part, prev, d_amax, amx)
                 saved["blocks"][bi] = None
                 if on_stage_done and (bi == 0 or stage_of[bi - 1] != stage_of[bi]):
                     self._join_wgrad()
@@ -367,17 +412,20 @@ class Engine:
             if on_stage_done:
                 on_stage_done("stem")
 
-    def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None):
-        """Backward of one residual block.  -> (gradient wrt the block input, BN-backward partial sums of it or None).
+    def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None, dout_amax=None, amx=None):
+        """Backward of one residual block.  -> (gradient wrt the block input, BN-backward partial sums of it or None,
+        absmax slot of it or None).
 
         Walks the convs last to first.  `g` is the gradient wrt the OUTPUT of bn_i (+ReLU): dout for the last BN (mask
         = block output > 0), the data gradient of conv_{i+1} for the inner ones (mask recomputed from raw_i).  For a
         stride-1 conv_i the BatchNorm backward of bn_i is applied inside the data-gradient kernel's input staging
         (IN_BNBWD): no separate apply pass; the kernel writes draw_i (for the weight gradient) and, for the last BN,
-        dz (the shortcut gradient) as side products.  Stride-2 convs (parity-class launches) keep the separate pass."""
+        dz (the shortcut gradient) as side products.  Stride-2 convs (parity-class launches) keep the separate pass.
+        amx (f16x3 backward): the step's absmax slot table; g / draw / dx each carry a slot (see Engine.backward)."""
         x, raws, out = rec["x"], rec["raws"], rec["out"]
         n = len(b.convs)
-        g, g_part, dz = dout, dout_partial, None
+        g, g_part, g_amax, dz = dout, dout_partial, dout_amax, None
+        take = (lambda: amx.take()) if amx is not None else (lambda: None)
         for i in range(n - 1, -1, -1):
             c, bn, raw = b.convs[i], b.bns[i], raws[i]
             last = i == n - 1
@@ -385,6 +433,7 @@ class Engine:
             in_aff = None if i == 0 else (b.bns[i - 1].t4[2], b.bns[i - 1].t4[3])
             hw = (inp.shape[1], inp.shape[2])
             act = out if last else None
+            f16 = amx is not None and c.k == 3            # this conv's data / weight gradients run with fp16 two-term operands
             # what this conv's data gradient must also do in its epilogue
             add_dz, bnb = False, None
             if i > 0:
@@ -396,11 +445,13 @@ class Engine:
                     bnb = (prev[0], x, prev[1])                         # statistics for the previous block's last BN
                     if rec.get("xmask") is not None:
                         bnb = bnb + (rec["xmask"],)                     # sign bits of x instead of x itself
+            res_amax, draw_amax = take(), take()
             if self.fuse_bn_apply and c.stride == 1 and c.cout >= self.fuse_apply_min_c:
                 if g_part is None:
                     g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
+                est = take() if f16 else None
                 coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,
-                                       bn.h.bias.grad, acc)
+                                       bn.h.bias.grad, acc, amax_in=g_amax, est_out=est)
                 draw = torch.empty_like(raw)
                 # the shortcut gradient dz = dout*[out > 0]: with an identity shortcut and sign masks it is never stored - the
                 # first conv's data-gradient epilogue re-forms it from dout and the mask bits
@@ -411,32 +462,37 @@ class Engine:
                     inb = inb + (rec["mask"],)                          # sign bits of the block output instead of it
                 if add_dz and lazy_dz:
                     res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
-                                         in_bnbwd=inb, side=(draw, dzb))
+                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax)
                 else:
                     res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                         in_bnbwd=inb, side=(draw, dzb))
+                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax)
                 if last:
                     dz = dzb
             else:
                 if last:
                     draw = ops.bn_backward(g, raw, out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
-                                           dz_out=g, accumulate=acc, partial=g_part)
+                                           dz_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax)
                     dz = g                                              # dout now holds dz
                 else:
                     draw = ops.bn_backward(g, raw, None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_RAW,
-                                           draw_out=g, accumulate=acc, partial=g_part)
-                res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb)
+                                           draw_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax)
+                res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb,
+                                     in_amax=draw_amax if f16 else None, out_amax=res_amax)
             g, g_part = res if bnb is not None else (res, None)
-            self._wgrad(inp, draw, c.h.weight.grad, c.k, c.stride, in_affine=in_aff, accumulate=acc)
-        dx, part = g, g_part
+            g_amax = res_amax
+            self._wgrad(inp, draw, c.h.weight.grad, c.k, c.stride, in_affine=in_aff, accumulate=acc,
+                        dy_amax=draw_amax if f16 else None, x_amax=rec["in_amax"][i] if f16 else None)
+        dx, part, dx_amax = g, g_part, g_amax
         if b.ds is not None:
             cd, bnd = b.ds
             drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
                                     MASK_NONE, draw_out=dz, accumulate=acc)
             self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
-            ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True)
+            # the 1x1 gradient lands on top of the 3x3 one: the same slot ends up >= the absmax of the sum's final values
+            ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True,
+                           out_amax=dx_amax)
             part = None
-        return dx, part
+        return dx, part, dx_amax
 
     # ---- fused training step (forward + CE + backward, no autograd graph) --------------------------------------
     def loss_and_grad(self, x, y, on_stage_done=None):

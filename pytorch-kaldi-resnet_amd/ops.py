@@ -34,6 +34,59 @@ def _iarr(v):
     return (ctypes.c_int * len(v))(*v)
 
 
+class AmaxPool:
+    """Slots for the absmax hand-offs of the f16x3 operand mode: one int32 (float bits, atomicMax'ed by the producing
+    kernel) per gradient tensor of a step, taken in a fixed order so that a captured hipGraph sees the same addresses on
+    every replay; zeroed once at the start of the step."""
+
+    def __init__(self, device, n=1024):
+        self.table = torch.zeros(n, device=device, dtype=torch.int32)
+        self.next = 0
+
+    def reset(self):
+        self.table.zero_()
+        self.next = 0
+
+    def take(self):
+        i = self.next
+        assert i < self.table.numel(), "AmaxPool exhausted"
+        self.next = i + 1
+        return self.table[i:i + 1]
+
+
+def absmax_into(t, slot):
+    """slot = max(slot, float bits of max|t|)  (spk_absmax: one pass over the tensor)"""
+    call("spk_absmax", ptr(t), ptr(slot), t.numel(), stream())
+    return slot
+
+
+def affine_estimate(scale, shift, amax_in, est):
+    """est = float bits of max_c|scale_c| * absmax + max_c|shift_c|: the bound of the values a convolution / weight gradient
+    with the fused input BatchNorm+ReLU stages, given the slot with the absmax of the raw tensor"""
+    call("spk_affine_estimate", ptr(scale), ptr(shift), scale.numel(), ptr(amax_in), ptr(est), stream())
+    return est
+
+
+def _amax_fwd_fallback(x, in_affine):
+    """Operand-scale input of a forward convolution / weight-gradient X operand called without one (tests, tools)."""
+    slot = absmax_into(x, torch.zeros(1, device=x.device, dtype=torch.int32))
+    if in_affine is None:
+        return slot
+    return affine_estimate(in_affine[0], in_affine[1], slot, torch.zeros(1, device=x.device, dtype=torch.int32))
+
+
+def _amax_fallback(dy, in_bnbwd):
+    """Operand-scale input of a data gradient called without one (tests, tools): absmax(dy), or for the fused
+    BatchNorm-backward form the same estimate bn_bwd_coef(est_out=) gives, from absmax(dy) and the coefficient rows."""
+    slot = torch.zeros(1, device=dy.device, dtype=torch.int32)
+    absmax_into(dy, slot)
+    if in_bnbwd is None:
+        return slot
+    est = torch.zeros(1, device=dy.device, dtype=torch.int32)
+    call("spk_bnbwd_estimate", ptr(in_bnbwd[3]), in_bnbwd[3].shape[1], ptr(slot), ptr(est), stream())
+    return est
+
+
 def conv_out_hw(h, w, ksize, stride):
     pad = 1 if ksize == 3 else 0
     return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
@@ -45,8 +98,10 @@ def conv_out_hw(h, w, ksize, stride):
 # the measured accuracy are fp32 in every mode (same test tolerances; tools/probe/split_probe.hip); bf16x6 is the default
 # because it runs the matrix phase at 16/6 of the fp32 rate.  Packed weights carry the mode: set it before the first
 # forward of a model (or mark its engine dirty).
-MFMA_MODES = {"f32": 0, "bf16x6": 6, "bf16x9": 9}
+MFMA_MODES = {"f32": 0, "bf16x6": 6, "bf16x9": 9, "f16x3": 3}
 SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "bf16x6")]
+# optional override for the backward kernels (data / weight gradients): None = same mode as the forward
+SPLIT_BWD = MFMA_MODES[os.environ["SPK_MFMA_BWD"]] if os.environ.get("SPK_MFMA_BWD") else None
 
 
 # wave-specialised (producer / consumer, persistent) convolution kernel, csrc/conv_ws_kernel.h: opt-in (SPK_CONV_WS=1).
@@ -58,25 +113,33 @@ WS_MIN_TAPS = int(os.environ.get("SPK_WS_MIN_TAPS", "9"))
 WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
-def split_for(ksize):
-    return SPLIT if ksize == 3 else 0
+def split_for(ksize, bwd=False):
+    """operand mode of a convolution launch: 3x3 only (1x1 convolutions and the stem stay on fp32 operands)"""
+    if ksize != 3:
+        return 0
+    return SPLIT_BWD if (bwd and SPLIT_BWD is not None) else SPLIT
 
 
 def pack_conv_weight(w, transpose=False, out=None):
     """OIHW nn.Conv2d weight -> MFMA fragment order (see csrc/conv_mfma.hip, csrc/conv_split.hip)."""
     Cout, Cin, KH, KW = w.shape
-    split = split_for(KH)
-    n = w.numel() * 3 // 2 if split else w.numel()      # three bf16 terms = 6 bytes per weight
+    split = split_for(KH, bwd=transpose)     # the transposed pack feeds the data gradient
+    n = packed_numel(w, bwd=transpose)
     if out is None or out.numel() != n:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
-    call("spk_pack_conv_weight_split" if split else "spk_pack_conv_weight", ptr(w), ptr(out), Cout, Cin, KH, KW,
-         1 if transpose else 0, stream(), label="spk_pack_conv_weight")
+    if split:
+        call("spk_pack_conv_weight_split", ptr(w), ptr(out), Cout, Cin, KH, KW, 1 if transpose else 0, split, stream(),
+             label="spk_pack_conv_weight")
+    else:
+        call("spk_pack_conv_weight", ptr(w), ptr(out), Cout, Cin, KH, KW, 1 if transpose else 0, stream(),
+             label="spk_pack_conv_weight")
     return out
 
 
-def packed_numel(w):
-    """floats of the packed form of an OIHW weight in the current operand mode."""
-    return w.numel() * 3 // 2 if split_for(w.shape[2]) else w.numel()
+def packed_numel(w, bwd=False):
+    """floats of the packed form of an OIHW weight in the current operand mode (three bf16 terms = 6 bytes per weight,
+    two fp16 terms or fp32 = 4 bytes)."""
+    return w.numel() * 3 // 2 if split_for(w.shape[2], bwd) in (6, 9) else w.numel()
 
 
 class PackTable:
@@ -90,8 +153,8 @@ class PackTable:
         self.key = []
         for w, wpk, transpose in jobs:
             Cout, Cin, KH, KW = w.shape
-            split = split_for(KH)
-            assert wpk.numel() == packed_numel(w) and w.is_contiguous()
+            split = split_for(KH, bwd=transpose)
+            assert wpk.numel() == packed_numel(w, bwd=transpose) and w.is_contiguous()
             blob += struct.pack("<QQ8i", w.data_ptr(), wpk.data_ptr(), Cout, Cin, KH * KW, 1 if transpose else 0, split,
                                 w.numel(), block0, 0)
             block0 += (w.numel() + 255) // 256
@@ -109,7 +172,7 @@ class PackTable:
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
-                 bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None):
+                 bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None, in_amax=None, out_amax=None, side_amax=None):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -125,7 +188,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
     # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
     ws, WC = None, 1
-    if split and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
+    if split in (6, 9) and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
         ws = WS_FORCE or tiling.ws_tile(*key)
     if ws is not None:
         TH, TW, MT, NT, WC = ws
@@ -178,7 +241,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(side[0]) if side else None, ptr(side[1]) if side else None,
          ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_bwd[1]) if (bn_bwd and bn_mask is None) else None,
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
-         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, stream(),
+         _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
+         stream(),
          label=("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
          else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
@@ -235,9 +299,13 @@ def _autotune_wgrad(key, x, dy, ksize, stride, in_affine):
 
 
 def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_add=None, relu=False, stats=False,
-             out=None):
-    """Forward conv on NHWC x with packed weights. Returns (out, stats_partial or None)."""
+             out=None, in_amax=None, out_amax=None):
+    """Forward conv on NHWC x with packed weights. Returns (out, stats_partial or None).
+    f16x3 operand mode: in_amax = slot with the float bits of the absmax of the STAGED values (x itself, or the
+    affine_estimate of relu(x*scale+shift) when in_affine is given); computed here with extra passes when omitted (tests)."""
     B, IH, IW, Cin = x.shape
+    if split_for(ksize) == 3 and in_amax is None:
+        in_amax = _amax_fwd_fallback(x, in_affine)
     OH, OW = conv_out_hw(IH, IW, ksize, stride)
     if out is None:
         out = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
@@ -246,12 +314,12 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
     else:
         taps = [(0, 0, 0)]
     st = _conv_launch(x, wpk, out, Cout, taps, stride, 1, 0, 0, OH, OW, in_affine, epi_affine, epi_add, relu, stats,
-                      split=split_for(ksize))
+                      split=split_for(ksize), in_amax=in_amax, out_amax=out_amax)
     return out, st
 
 
 def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None, in_bnbwd=None,
-               side=None, add_mask=None):
+               side=None, add_mask=None, in_amax=None, out_amax=None, side_amax=None):
     """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
     `add` (same shape as dx) is summed in the epilogue (only where the bits of `add_mask`, sign-mask words of the same
     shape, are set when that is given); accumulate=True adds onto the existing `out`.
@@ -259,8 +327,14 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
     (+ReLU); the launch also returns the BatchNorm-backward partial sums -> (dx, partial).
     in_bnbwd = (raw, act or None, bn4[4][Cout], coef[3][Cout]) + side = (draw_out, dz_out or None) (stride-1 only): `dy` is
     the gradient wrt a BatchNorm(+ReLU) OUTPUT; the BatchNorm backward is applied while staging and the gradient wrt
-    the raw conv output is also written to draw_out (and dy*mask to dz_out)."""
+    the raw conv output is also written to draw_out (and dy*mask to dz_out).
+    f16x3 operand mode: in_amax = 1-element int32 tensor with the float bits of absmax(staged tensor) - for in_bnbwd an upper
+    estimate of the BatchNorm-backward values (bn_bwd_coef(..., est_out=)) - that fixes the power-of-two operand scale; when
+    omitted it is computed here with an extra pass (tests / tools; the engine always passes it).  out_amax / side_amax: slots
+    the launch atomically maxes |dx| / |draw_out| into (float bits) for the kernels that consume those tensors."""
     B, OH, OW, Cout = dy.shape
+    if split_for(ksize, True) == 3 and in_amax is None:
+        in_amax = _amax_fallback(dy, in_bnbwd)
     IH, IW = in_hw
     if out is None:
         assert not accumulate
@@ -274,7 +348,8 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
         else:
             taps = [(0, 0, 0)]
         st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd, in_bnbwd,
-                          side, split=split_for(ksize), add_mask=add_mask)
+                          side, split=split_for(ksize, True), add_mask=add_mask, in_amax=in_amax, out_amax=out_amax,
+                          side_amax=side_amax)
         return (out, st) if bn_bwd is not None else out
     assert stride == 2 and bn_bwd is None and in_bnbwd is None and add_mask is None
     if ksize == 1:
@@ -285,7 +360,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             else:
                 out.zero_()
         _conv_launch(dy, wpk_t, out, Cin, [(0, 0, 0)], 1, 2, 0, 0, (IH + 1) // 2, (IW + 1) // 2, None, None, out, False,
-                     False)
+                     False, out_amax=out_amax)
         return out
     for cy in range(2):
         for cx in range(2):
@@ -300,7 +375,8 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
                     if (cx + 1 - kw) % 2:
                         continue
                     taps.append(((cy + 1 - kh) // 2, (cx + 1 - kw) // 2, kh * 3 + kw))
-            _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False, split=split_for(3))
+            _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False, split=split_for(3, True),
+                         in_amax=in_amax, out_amax=out_amax)
     return out
 
 
@@ -332,15 +408,21 @@ def _workspace_named(name, nbytes, device):
     return w
 
 
-def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
-    """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy."""
+def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None):
+    """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy.  f16x3 operand mode: dy_amax = slot with the float
+    bits of absmax(dy) (computed here with an extra pass when omitted: tests / tools)."""
     B, IH, IW, Cin = x.shape
     _, OH, OW, Cout = dy.shape
+    split = split_for(ksize, True)
+    if split == 3 and dy_amax is None:
+        dy_amax = absmax_into(dy, torch.zeros(1, device=dy.device, dtype=torch.int32))
+    if split == 3 and x_amax is None:
+        x_amax = _amax_fwd_fallback(x, in_affine)
     wkey = (OH, OW, Cin, Cout, ksize, stride)
     if tiling.AUTOTUNE and wkey not in tiling.FORCE_WGRAD and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         tiling.FORCE_WGRAD[wkey] = tiling._wgrad_tile(*wkey)      # placeholder: stops the recursion below
         _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
-    TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split_for(ksize))
+    TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split)
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
@@ -348,17 +430,17 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False):
     flags = IN_AFFINE_RELU if in_affine is not None else 0
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
-         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split_for(ksize),
-         stream(),
+         B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
+         ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
          label=("conv_wgrad_split_kernel<%d,%d,%d,%d>" % (
-             4 // WN, WN, split_for(ksize), 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split_for(ksize)
+             4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw
 
 
-def stem_fwd(x, w, epi_affine=None, relu=False, stats=False):
+def stem_fwd(x, w, epi_affine=None, relu=False, stats=False, amax_out=None):
     """x [B][F][T] -> [B][F][T][32] (+ stats partial [nblk][32][2])."""
     B, F, T = x.shape
     out = torch.empty(B, F, T, 32, device=x.device, dtype=torch.float32)
@@ -367,7 +449,8 @@ def stem_fwd(x, w, epi_affine=None, relu=False, stats=False):
     if stats:
         st = torch.empty(hip.lib().spk_stem_fwd_blocks(B, F, T), 32, 2, device=x.device, dtype=torch.float32)
     call("spk_stem_conv_fwd", ptr(x), ptr(w), ptr(out), ptr(st),
-         ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None, B, F, T, flags, stream())
+         ptr(epi_affine[0]) if epi_affine else None, ptr(epi_affine[1]) if epi_affine else None, B, F, T, flags, ptr(amax_out),
+         stream())
     return out, st
 
 
@@ -412,7 +495,7 @@ def bn_eval_coeffs(gamma, beta, rm, rv, out2):
     call("spk_bn_eval_coeffs", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(out2[0]), ptr(out2[1]), C, BN_EPS, stream())
 
 
-def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, mask=False):
+def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, mask=False, amax_out=None):
     """out = [relu](raw*scale + shift [+ res | + res*rscale + rshift]).  mask=True also returns the sign bits of `out`
     ([N][C/32] int32 words): the backward pass reads those instead of the activated tensor."""
     C = raw.shape[-1]
@@ -422,12 +505,12 @@ def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, 
     mk = torch.empty(N * (C // 32), device=raw.device, dtype=torch.int32) if mask else None
     call("spk_bn_apply", ptr(raw), ptr(scale), ptr(shift), ptr(res),
          ptr(res_affine[0]) if res_affine else None, ptr(res_affine[1]) if res_affine else None, ptr(out), ptr(mk), N, C,
-         1 if relu else 0, stream())
+         1 if relu else 0, ptr(amax_out), stream())
     return (out, mk) if mask else out
 
 
 def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,
-                partial=None):
+                partial=None, amax_out=None):
     """Full BN backward (reduce -> finalize -> apply). bn4 = [mean, invstd, scale, shift] rows.
     `partial`: (sum dz, sum dz*xhat) rows already produced by the data-gradient epilogue (EPI_BNBWD) - skips the
     reduction pass.  Returns draw (gradient wrt the raw conv output)."""
@@ -446,16 +529,20 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
-         ptr(draw_out), ptr(dz_out), N, C, mask_mode, stream())
+         ptr(draw_out), ptr(dz_out), N, C, mask_mode, ptr(amax_out), stream())
     return draw_out
 
 
-def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False):
-    """BatchNorm-backward finalize only: dgamma, dbeta and the coefficient rows [gamma*invstd, mean(dz), mean(dz*xhat)]."""
+def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, amax_in=None, est_out=None):
+    """BatchNorm-backward finalize only: dgamma, dbeta and the coefficient rows [gamma*invstd, mean(dz), mean(dz*xhat)].
+    amax_in + est_out (f16x3 mode): also the upper estimate of the values the fused BatchNorm-backward data gradient will
+    stage (spk_bnbwd_estimate), from the absmax of the incoming gradient."""
     C = gamma.numel()
     coef = torch.empty(3, C, device=gamma.device, dtype=torch.float32)
     call("spk_bn_bwd_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(bn4[1]), ptr(dgamma),
          ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), stream())
+    if est_out is not None:
+        call("spk_bnbwd_estimate", ptr(coef), C, ptr(amax_in), ptr(est_out), stream())
     return coef
 
 

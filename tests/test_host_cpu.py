@@ -304,6 +304,18 @@ def test_tile_lookup_by_mode_and_operand_mode(monkeypatch):
 
 def test_operand_modes_are_declared():
     from pytorch_kaldi_resnet_amd import ops
-    assert ops.MFMA_MODES == {"f32": 0, "bf16x6": 6, "bf16x9": 9}
+    assert ops.MFMA_MODES == {"f32": 0, "bf16x6": 6, "bf16x9": 9, "f16x3": 3}
     assert ops.SPLIT in ops.MFMA_MODES.values()
     assert ops.split_for(1) == 0 and ops.split_for(3) == ops.SPLIT      # 1x1 convolutions always use fp32 operands
+    assert ops.split_for(1, bwd=True) == 0 and ops.split_for(3, bwd=True) == (ops.SPLIT if ops.SPLIT_BWD is None else ops.SPLIT_BWD)
+    import torch
+    w = torch.zeros(64, 32, 3, 3)
+    old = (ops.SPLIT, ops.SPLIT_BWD)
+    try:
+        for mode, n in (("f32", w.numel()), ("bf16x6", w.numel() * 3 // 2), ("f16x3", w.numel())):
+            ops.SPLIT, ops.SPLIT_BWD = ops.MFMA_MODES[mode], None
+            assert ops.packed_numel(w) == n and ops.packed_numel(w, bwd=True) == n       # 4 / 6 / 4 bytes per weight
+        ops.SPLIT, ops.SPLIT_BWD = 3, 6       # forward on fp16 terms, gradients on bf16 terms: the two packs differ
+        assert ops.packed_numel(w) == w.numel() and ops.packed_numel(w, bwd=True) == w.numel() * 3 // 2
+    finally:
+        ops.SPLIT, ops.SPLIT_BWD = old

@@ -63,7 +63,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=["f32", "bf16x6", "bf16x9"])
+@pytest.fixture(params=["f32", "bf16x6", "bf16x9", "f16x3"])
 def mfma_mode(request, ops):
     """operand mode of the 3x3 convolutions: native fp32 MFMA, or fp32 operands split into three bf16 terms with the 6 /
     9 cross terms on the bf16 MFMA (fp32 accumulate).  Every mode must meet the SAME tolerances below."""

@@ -42,7 +42,7 @@ def loss_curve_tol(gold_dir, name):
 CASES = ["c1_r34_aam", "r34_aam_t203", "r34_aam_t300", "r34_softmax_mean_f40", "r34_aamv1_f40", "r101_aam"]
 
 
-@pytest.fixture(autouse=True, params=["bf16x6", "f32"])
+@pytest.fixture(autouse=True, params=["bf16x6", "f32", "f16x3"])
 def mfma_mode(request):
     """Every model-level parity test runs in the default operand mode (fp32 operands as three bf16 terms, 6 cross products
     on the bf16 matrix instruction, fp32 accumulate) and on the native fp32 matrix instruction - same tolerances."""

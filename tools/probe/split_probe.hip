@@ -26,12 +26,42 @@ static __device__ __forceinline__ void split3(const float* v, s16x8& s1, s16x8& 
     }
 }
 
-__global__ void split_probe_kernel(const float* A, const float* B, float* C, int K, int variant, int reps) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// fp16 two-term split of v * sigma (sigma a power of two): u = h1 + h2 + O(2^-22 |u|); saturating
+static __device__ __forceinline__ void split2h(const float* v, float sigma, f16x8& h1, f16x8& h2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float u = v[i] * sigma;
+        u = fminf(fmaxf(u, -65504.f), 65504.f);
+        const _Float16 a = (_Float16)u;
+        h1[i] = a;
+        h2[i] = (_Float16)(u - (float)a);
+    }
+}
+
+__global__ void split_probe_kernel(const float* A, const float* B, float* C, int K, int variant, int reps, float sa_, float sb_) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     f32x16 acc;
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int rep = 0; rep < reps; ++rep) {
-        if (variant == 0) {
+        if (variant == 23 || variant == 24) {
+            // variant 23: h1g1 + h1g2 + h2g1 (3 products); 24: + h2g2
+            for (int k = 0; k < K; k += 16) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    av[i] = A[r * K + k + 8 * h + i];
+                    bv[i] = B[(k + 8 * h + i) * 32 + r];
+                }
+                f16x8 a1, a2, b1, b2;
+                split2h(av, sa_, a1, a2);
+                split2h(bv, sb_, b1, b2);
+                if (variant == 24) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+            }
+        } else if (variant == 0) {
             for (int k = 0; k < K; k += 2)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * K + k + h], B[(k + h) * 32 + r], acc, 0, 0, 0);
         } else {
@@ -61,11 +91,11 @@ __global__ void split_probe_kernel(const float* A, const float* B, float* C, int
     }
     for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        C[row * 32 + r] = acc[e];
+        C[row * 32 + r] = (variant == 23 || variant == 24) ? acc[e] / (sa_ * sb_) : acc[e];
     }
 }
 
-extern "C" int split_probe(const float* A, const float* B, float* C, int K, int variant, int reps, void* stream) {
-    hipLaunchKernelGGL(split_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C, K, variant, reps);
+extern "C" int split_probe(const float* A, const float* B, float* C, int K, int variant, int reps, void* stream, float sa, float sb) {
+    hipLaunchKernelGGL(split_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C, K, variant, reps, sa, sb);
     return (int)hipGetLastError();
 }
