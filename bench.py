@@ -72,8 +72,9 @@ def parse():
                     help="one chunk length per step, uniform in [LO, HI] (seeded) like the reference's variable-length "
                          "batches (scripts/datasets.py:178-193); implies eager launches")
     ap.add_argument("--mfma", choices=["f16x3", "bf16x6", "bf16x9", "f32"], default=None,
-                    help="operand mode of the 3x3 convolutions (default: the package default, bf16x6 = fp32 operands as three "
-                         "exact bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate; f32 = native fp32 MFMA)")
+                    help="operand mode of the 3x3 convolutions (default: the package default, f16x3 = fp32 operands as two fp16 "
+                         "terms of value x 2^k, 3 cross products on the fp16 MFMA, fp32 accumulate; bf16x6 = three exact bf16 "
+                         "terms, 6 cross products; f32 = native fp32 MFMA)")
     ap.add_argument("--autotune", action="store_true", help="time candidate tiles on first use of a launch shape (SPK_AUTOTUNE=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

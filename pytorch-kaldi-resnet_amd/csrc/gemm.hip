@@ -97,9 +97,9 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ part, float*
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * N) return;
     const int m = i / N, n = i - m * N;
-    float v = 0.f;
-    for (int z = 0; z < nsplit; ++z) v += part[(size_t)z * M * N + i];
-    v *= alpha;
+    double acc = 0.0;                      // the slices are few: folding them in fp64 costs nothing and removes one rounding chain
+    for (int z = 0; z < nsplit; ++z) acc += (double)part[(size_t)z * M * N + i];
+    float v = (float)acc * alpha;
     if (bias) v += bias[n];
     float* dst = Cm + m * ldc + n;
     *dst = accumulate ? *dst + v : v;

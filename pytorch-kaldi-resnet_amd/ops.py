@@ -92,14 +92,19 @@ def conv_out_hw(h, w, ksize, stride):
     return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
 
 
-# Matrix-core operand mode of the 3x3 convolutions (forward, data gradient, weight gradient): 0 = fp32 operands on
-# v_mfma_f32_32x32x2_f32; 6 / 9 = each fp32 operand split exactly into three bf16 terms, 6 (or all 9) cross terms on
-# v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/conv_kernel.h, csrc/conv_wgrad_split.hip).  Inputs, outputs and
-# the measured accuracy are fp32 in every mode (same test tolerances; tools/probe/split_probe.hip); bf16x6 is the default
-# because it runs the matrix phase at 16/6 of the fp32 rate.  Packed weights carry the mode: set it before the first
+# Matrix-core operand mode of the 3x3 convolutions (forward, data gradient, weight gradient).  Inputs, outputs, accumulation
+# and the measured accuracy are fp32 in every mode (same test tolerances; tools/probe/split_probe.hip):
+#   f32     fp32 operands on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak)
+#   bf16x6  every fp32 operand split exactly into three bf16 terms, the 6 cross terms of weight >= 2^-16 on
+#   bf16x9    v_mfma_f32_32x32x16_bf16 (bf16x9: all nine) - 16/6 of the fp32 matrix rate
+#   f16x3   (default) operand value x 2^k as two fp16 terms (2 x 11 significand bits; k from the tensor's absmax, handed from
+#           the kernel that writes a tensor to the kernels that read it), the three cross terms h1g1 + h1g2 + h2g1 on
+#           v_mfma_f32_32x32x16_f16, accumulators scaled back by 2^-(ka+kb) - half the matrix instructions of bf16x6; the
+#           step is power-limited on MI355X, so this is where the time goes (78 -> 59 ms per step)
+# csrc/conv_kernel.h, csrc/conv_wgrad_split.hip, csrc/spk_common.h.  Packed weights carry the mode: set it before the first
 # forward of a model (or mark its engine dirty).
 MFMA_MODES = {"f32": 0, "bf16x6": 6, "bf16x9": 9, "f16x3": 3}
-SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "bf16x6")]
+SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "f16x3")]
 # optional override for the backward kernels (data / weight gradients): None = same mode as the forward
 SPLIT_BWD = MFMA_MODES[os.environ["SPK_MFMA_BWD"]] if os.environ.get("SPK_MFMA_BWD") else None
 

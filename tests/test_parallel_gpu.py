@@ -48,7 +48,7 @@ class _Recorder:
         self.snaps[name] = self.model.flat_grads()[lo:hi].clone()
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
 def test_two_shards_average_like_ddp(gold_dir, mode):
     from pytorch_kaldi_resnet_amd import ops
     from pytorch_kaldi_resnet_amd.optim import FlatSGD
