@@ -85,12 +85,13 @@ if args.sweep_bnbwd:
         wpk_t = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=dev) * 0.05, True)
         flops = 2.0 * B * H * W * C * C * 9
         key = (H, W, 1, 3, 3, 9, C)
+        est = ops._amax_fallback(dy, (raw, act, bn4, coef)) if ops.SPLIT == 3 else None
         res = []
         for cand in conv_candidates(H, W, 1, 3, C):
             FORCE[key + (1,)] = cand
             try:
                 ms = timeit(lambda: ops.conv_dgrad(dy, wpk_t, C, 3, 1, (H, W), out=dx, bn_bwd=(raw_p, None, bn4),
-                                                   in_bnbwd=(raw, act, bn4, coef), side=(draw, dz)), args.reps)
+                                                   in_bnbwd=(raw, act, bn4, coef), side=(draw, dz), in_amax=est), args.reps)
             except RuntimeError:
                 continue
             res.append((ms, cand))
@@ -115,6 +116,9 @@ for name, Cin, Cout, H, W, k, s in shapes:
     out = torch.empty(B, OH, OW, Cout, device=dev)
     dx = torch.empty(B, H, W, Cin, device=dev)
     flops = 2.0 * B * OH * OW * Cout * Cin * k * k
+    # absmax slots of the f16x3 operand mode, computed once (the engine hands them from kernel to kernel)
+    xa = ops._amax_fwd_fallback(x, None) if ops.SPLIT == 3 else None
+    dya = ops.absmax_into(dy, torch.zeros(1, device=dev, dtype=torch.int32)) if ops.SPLIT == 3 else None
     key = (OH, OW, s if k == 3 else 1, k, k, k * k, Cout)      # strided 1x1 launches run as IS = 1 over a strided view
     if args.sweep and not args.wgrad_only and (k == 3 or not ops.SPLIT):
         res = []
@@ -122,7 +126,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
         for cand in conv_candidates(OH, OW, s if k == 3 else 1, k, Cout):
             tab[key] = cand
             try:
-                ms = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
+                ms = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out, in_amax=xa), args.reps)
             except RuntimeError as e:
                 continue
             res.append((ms, cand))
@@ -150,7 +154,7 @@ for name, Cin, Cout, H, W, k, s in shapes:
             for _, TH, TW in cands[:16]:
                 tiling.FORCE_WGRAD[wkey] = (TH, TW, WN)
                 try:
-                    ms = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
+                    ms = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s, dy_amax=dya, x_amax=xa), args.reps)
                 except RuntimeError:
                     continue
                 res.append((ms, (TH, TW, WN)))
@@ -159,9 +163,9 @@ for name, Cin, Cout, H, W, k, s in shapes:
         table["wgrad_split" if (ops.SPLIT and k == 3) else "wgrad"][",".join(map(str, wkey))] = list(res[0][1])
         print("%-12s wgrad best %s %.3f ms %.1f TF | top: %s" % (name, res[0][1], res[0][0], flops / res[0][0] / 1e9,
               " ".join("%s:%.3f" % (c, m) for m, c in res[:5])), flush=True)
-    t_fwd = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out), args.reps)
-    t_dg = timeit(lambda: ops.conv_dgrad(dy, wpk_t, Cin, k, s, (H, W), out=dx), args.reps)
-    t_wg = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s), args.reps)
+    t_fwd = timeit(lambda: ops.conv_fwd(x, wpk, Cout, k, s, stats=True, out=out, in_amax=xa), args.reps)
+    t_dg = timeit(lambda: ops.conv_dgrad(dy, wpk_t, Cin, k, s, (H, W), out=dx, in_amax=dya), args.reps)
+    t_wg = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s, dy_amax=dya, x_amax=xa), args.reps)
     rows.append((name, flops, t_fwd, t_dg, t_wg))
     print("%-12s %6.1f GF  fwd %.3f ms %5.1f TF  dgrad %.3f ms %5.1f TF  wgrad %.3f ms %5.1f TF   tiles %s / %s" % (
         name, flops / 1e9, t_fwd, flops / t_fwd / 1e9, t_dg, flops / t_dg / 1e9, t_wg, flops / t_wg / 1e9,
