@@ -47,8 +47,8 @@ def mfma_peak(kernel_label):
         terms = int(inner[3])
     elif kernel_label.startswith("conv_ws_kernel") and len(inner) == 5:
         terms = int(inner[4])
-    elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 4:
-        terms = int(inner[2])
+    elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 5:
+        terms = int(inner[3])
     if terms:
         return PEAK_BF16_MFMA_TFLOPS / terms, "%s dense peak / %d cross products per fp32 multiply-add" % (
             "fp16" if terms == 3 else "bf16", terms)

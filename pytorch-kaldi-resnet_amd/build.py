@@ -15,6 +15,8 @@ def csrc_fingerprint():
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
+        if not os.path.isfile(os.path.join(CSRC, f)):
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]

@@ -85,7 +85,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.in_mask = in_mask; a.bn_mask = bn_mask; a.add_mask = add_mask;
     a.in_amax = in_amax; a.out_amax = out_amax; a.side_amax = side_amax;
     a.in_sigma = SPK_F16_ACT_SIGMA; a.w_sigma = SPK_F16_W_SIGMA;
-    SPK_REQUIRE(!(flags & SPK_CONV_WS) || split != 3, "spk_conv_mfma: the wave-specialised kernel has no f16x3 instantiation");
+
     SPK_REQUIRE(!add_mask || ((flags & SPK_EPI_ADD) && Cout % 32 == 0), "spk_conv_mfma: add_mask needs EPI_ADD and Cout %% 32 == 0");
     SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);
     a.B = B; a.IHp = IH; a.IWp = IW; a.ips = ips; a.IH = (IH + ips - 1) / ips; a.IW = (IW + ips - 1) / ips; a.Cin = Cin; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf; a.Cout = Cout;
@@ -131,7 +131,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     if (flags & SPK_CONV_WS) {
         SPK_REQUIRE(split != 0 && kc == 1 && ntaps == 9, "spk_conv_mfma: the wave-specialised kernel needs bf16-split operands, 9 taps and kc = 1");
         for (int t = 0; t < 9; ++t) {
-            const long long off = (long long)a.tap_w[t] * (Cin >> 4) * 3 * (Cout >> 5) * 256;     // [tap][Cin/16][term][Cout/32][256 floats]
+            const long long off = (long long)a.tap_w[t] * (Cin >> 4) * nterm * (Cout >> 5) * 256;     // [tap][Cin/16][term][Cout/32][256 floats]
             SPK_REQUIRE(off < 2147483647LL, "spk_conv_mfma: packed weight offset overflows");
             a.tap_boff[t] = (int)off;
         }

@@ -21,7 +21,7 @@ int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, i
         if (split == 6) return launch_split<M, N, 6>(a, lds_bytes, st); \
         return launch_split<M, N, 9>(a, lds_bytes, st);                 \
     }
-    CASE(1, 1) CASE(2, 1) CASE(3, 1) CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(1, 4)
+    CASE(1, 1) CASE(2, 1) CASE(3, 1) CASE(4, 1) CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(1, 4)
 #undef CASE
     spk_set_error("spk_conv_mfma: unsupported split tile config MT=%d NT=%d", MT, NT);
     return -1;

@@ -293,7 +293,8 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.tw_magic = (unsigned)((0x100000000ULL + (unsigned long long)TW - 1) / (unsigned long long)TW);
     a.flags = flags;
     a.dy_amax = dy_amax; a.x_amax = x_amax;
-    SPK_REQUIRE(split == 0 || ((split == 3 || split == 6 || split == 9) && ksize == 3), "spk_conv_wgrad: split=%d (0, or 3 / 6 / 9 for 3x3)", split);
+    SPK_REQUIRE(split == 0 || split == 3 || ((split == 6 || split == 9) && ksize == 3),
+                "spk_conv_wgrad: split=%d (0; 3 = f16x3, any kernel size; 6 / 9 = bf16 terms, 3x3 only)", split);
     SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",
                 a.halo_h, a.halo_w, 32 * WGRAD_NX);
     SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",

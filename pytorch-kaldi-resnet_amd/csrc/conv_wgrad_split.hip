@@ -23,10 +23,11 @@ static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int WK, int WN, int SPLIT, int NX>
+// NTAPS = 9: 3x3 (pad 1); NTAPS = 1: 1x1 (pad 0; the f16x3 mode also runs the Bottleneck / downsample 1x1 convolutions here)
+template <int NTAPS, int WK, int WN, int SPLIT, int NX>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    constexpr int NTAPS = 9;
+    constexpr int KS = NTAPS == 9 ? 3 : 1;
     constexpr int PX = 192;                               // X bytes per staged pixel: [3 terms][32 ch bf16]
     constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);      // dY bytes per pixel: [WN][3 terms][32 ch bf16] (+ pad)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
             for (int s = 0; s < NTERM; ++s) bf[s] = tr_read8(dys + da[0] + s * 64, dys + da[1] + s * 64);
             s16x8 a0[NTERM], a1[NTERM];
             auto load_a = [&](s16x8* af, int t) {
-                const int toff = ((t / 3) * a.halo_w + (t % 3)) * PX;
+                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX;
 #pragma unroll
                 for (int s = 0; s < NTERM; ++s) af[s] = tr_read8(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
             };
@@ -254,32 +255,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     }
 }
 
-template <int WK, int WN>
+template <int NTAPS, int WK, int WN>
 static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
     const int npix_pad = ((a.TH * a.TW + 15) >> 4) << 4;
     constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);
     size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 192 + (size_t)npix_pad * PD;
-    const size_t red_bytes = (WK > 1) ? (size_t)WN * 9 * 16 * 64 * sizeof(float) : 0;
+    const size_t red_bytes = (WK > 1) ? (size_t)WN * NTAPS * 16 * 64 * sizeof(float) : 0;
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(split): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
     const bool small = a.halo_h * a.halo_w <= 32 * 4;
     if (split == 3) {
-        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 3, 4>), grid, dim3(256), lds_bytes, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 3, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
-    } else if (split == 6) {
-        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, 4>), grid, dim3(256), lds_bytes, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 6, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, 4>), grid, dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+    } else if constexpr (NTAPS == 9) {
+        if (split == 6) {
+            if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<9, WK, WN, 6, 4>), grid, dim3(256), lds_bytes, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_split_kernel<9, WK, WN, 6, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+        } else {
+            if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<9, WK, WN, 9, 4>), grid, dim3(256), lds_bytes, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_split_kernel<9, WK, WN, 9, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+        }
     } else {
-        if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9, 4>), grid, dim3(256), lds_bytes, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_split_kernel<WK, WN, 9, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
+        spk_set_error("spk_conv_wgrad(split): 1x1 weight gradients exist in the f16x3 mode only");
+        return -1;
     }
     SPK_LAUNCH_CHECK("spk_conv_wgrad(split)");
     return 0;
 }
 
 int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st) {
-    if (WN == 1) return launch_one<4, 1>(a, split, st);
-    if (WN == 2) return launch_one<2, 2>(a, split, st);
-    return launch_one<1, 4>(a, split, st);
+    if (a.KW == 1) {
+        if (WN == 1) return launch_one<1, 4, 1>(a, split, st);
+        if (WN == 2) return launch_one<1, 2, 2>(a, split, st);
+        return launch_one<1, 1, 4>(a, split, st);
+    }
+    if (WN == 1) return launch_one<9, 4, 1>(a, split, st);
+    if (WN == 2) return launch_one<9, 2, 2>(a, split, st);
+    return launch_one<9, 1, 4>(a, split, st);
 }

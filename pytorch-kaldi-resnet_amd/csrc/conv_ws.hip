@@ -36,6 +36,7 @@ int spk_launch_conv_ws(const ConvArgs& a, int MT, int NT, int WC, int split, int
     SPK_REQUIRE(a.kc == 1, "spk_conv_mfma(ws): kc must be 1");
 #define CASE(M, N, W)                                                   \
     if (MT == M && NT == N && WC == W) {                                \
+        if (split == 3) return launch_ws<M, N, W, 3>(a, lds_bytes, st); \
         if (split == 6) return launch_ws<M, N, W, 6>(a, lds_bytes, st); \
         return launch_ws<M, N, W, 9>(a, lds_bytes, st);                 \
     }

@@ -46,9 +46,9 @@ template <int MT, int NT, int WC, bool BNBWD, int SPLIT>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     static_assert(WC == 1 || WC == 2 || WC == 4, "consumer waves: WP x WC = 4");
     constexpr int WP = 4 / WC;
-    static_assert(SPLIT == 6 || SPLIT == 9, "wave-specialised kernel: bf16-split operands only");
+    static_assert(SPLIT == 3 || SPLIT == 6 || SPLIT == 9, "wave-specialised kernel: split operands only");
     using Cfg = ConvCfg<SPLIT>;
-    constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4;
+    constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,6 +65,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     };
     int k = 0;                                    // work-item counter of this block: ring slot = k & 1
+    // f16x3: input scale (a power of two) and the factor that takes the accumulators back to fp32 units
+    float sig = 1.f, inv_sig = 1.f;
+    if constexpr (SPLIT == 3) {
+        sig = a.in_amax ? spk_sigma_from_amax_bits(*a.in_amax) : a.in_sigma;
+        inv_sig = 1.f / (sig * a.w_sigma);
+    }
     // per-tap table in LDS, behind the ring and the epilogue slabs: [0..11] A-fragment offset of the tap inside a slot
     // (16-byte units), [16..27] float offset of the tap's weight fragments; entries 9..11 repeat tap 8 (harmless prefetches)
     int* tapt = (int*)(lds + 2 * slot_floats + 4 * 32 * (NT * 32 + 4));
@@ -80,13 +86,21 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         const int ptid = tid - 256;
         const int quad = ptid & (TPP - 1);        // this thread's float4 of channels within a staged pixel
         const int prow = ptid / TPP;              // and its pixel slot within a staging pass
+        float side_mx = 0.f;
         auto store_px = [&](float* plane, int p, f32x4 w) {
-            uint2 t0, t1, t2;
-            split3(w, t0, t1, t2);
             uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][CK ch]: CK*2 bytes per term
-            dst[0] = t0;
-            dst[CK / 4] = t1;
-            dst[CK / 2] = t2;
+            if constexpr (SPLIT == 3) {
+                uint2 t0, t1;
+                split2h(w, sig, t0, t1);
+                dst[0] = t0;
+                dst[CK / 4] = t1;
+            } else {
+                uint2 t0, t1, t2;
+                split3(w, t0, t1, t2);
+                dst[0] = t0;
+                dst[CK / 4] = t1;
+                dst[CK / 2] = t2;
+            }
         };
         for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
             const int bid = tile_of(v);
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                                 if (owner && core[u]) {
                                     *(f32x4*)(a.side_draw + off[u]) = w;
                                     if (a.side_dz) *(f32x4*)(a.side_dz + off[u]) = dz;
+                                    side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                                 }
                             }
                         }
@@ -198,6 +213,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 }
                 ws_barrier();      // B_k: slot k & 1 is full; the consumers are done with the other slot
             }
+        }
+        if constexpr (BNBWD) {
+            if (a.side_amax) spk_wave_amax_commit(side_mx, a.side_amax);
         }
         return;
     }
@@ -257,8 +275,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         for (int ch = 0; ch < nchunks; ++ch, ++k) {
             const f32x4* lds4 = (const f32x4*)(lds + (k & 1) * slot_floats);
             // packed weights: [tap][Cin/16][term][Cout/32][64 lanes][8 bf16]; tap_boff[t] = float offset of (tap, plane 0)
-            const float* wchunk = a.wpk + ((size_t)ch * 3 * cout32 + (cg * WC + wc) * NT) * 256;
-            f32x4 bq[3][3][NT], aq[3][3];
+            const float* wchunk = a.wpk + ((size_t)ch * NTERM * cout32 + (cg * WC + wc) * NT) * 256;
+            f32x4 bq[3][NTERM][NT], aq[3][NTERM];
             auto load_b = [&](int buf, int boff) {
 #ifdef WS_ABL_B_SAMEADDR
                 const float* wp = a.wpk + (boff & 1);      // diagnostic: an L1-hot address every step (wrong results)
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 const float* wp = wchunk + boff;
 #endif
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NTERM; ++s)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
 #ifdef WS_ABL_NO_BLOAD
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             };
             auto load_a = [&](int set, int toff, int i) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
+                for (int s = 0; s < NTERM; ++s) {
 #ifdef WS_ABL_NO_ALOAD
                     asm volatile("" : "+v"(aq[set][s]) : "s"(toff));
 #else
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             };
 #if defined(WS_ABL_NO_BLOAD) || defined(WS_ABL_NO_ALOAD)
             for (int u = 0; u < 3; ++u)
-                for (int s = 0; s < 3; ++s) {
+                for (int s = 0; s < NTERM; ++s) {
                     for (int j = 0; j < NT; ++j) bq[u][s][j] = (f32x4){1.f, 2.f, 3.f, 4.f};
                     aq[u][s] = (f32x4){1.f, 2.f, 3.f, 4.f};
                 }
@@ -311,16 +329,22 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                         else load_a((MT * u + i + 2) % 3, o_next, i + 2 - MT);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int sum = (SPLIT == 9 ? 4 : 2); sum >= 0; --sum)
+                        for (int sum = Cfg::MAXSUM; sum >= 0; --sum)
 #pragma unroll
-                            for (int sa = 0; sa < 3; ++sa) {
+                            for (int sa = 0; sa < NTERM; ++sa) {
                                 const int sb = sum - sa;
-                                if (sb < 0 || sb > 2) continue;
+                                if (sb < 0 || sb >= NTERM) continue;
 #pragma unroll
-                                for (int j = 0; j < NT; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                        __builtin_bit_cast(bf16x8, aq[(MT * u + i) % 3][sa]), __builtin_bit_cast(bf16x8, bq[u % 3][sb][j]),
-                                        acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < NT; ++j) {
+                                    if constexpr (SPLIT == 3)
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                            __builtin_bit_cast(f16x8, aq[(MT * u + i) % 3][sa]), __builtin_bit_cast(f16x8, bq[u % 3][sb][j]),
+                                            acc[i][j], 0, 0, 0);
+                                    else
+                                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                            __builtin_bit_cast(bf16x8, aq[(MT * u + i) % 3][sa]), __builtin_bit_cast(bf16x8, bq[u % 3][sb][j]),
+                                            acc[i][j], 0, 0, 0);
+                                }
                             }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -345,6 +369,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             bsh = *(const f32x4*)(a.bn4 + 3 * a.Cout + n0 + qc * 4);
         }
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        float out_mx = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -352,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    slab[row * LW + j * 32 + r] = acc[i][j][e];
+                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig : acc[i][j][e];
                 }
             // All global loads of the m-tile's epilogue (shortcut gradient, raw conv output of the BatchNorm whose backward
             // statistics are reduced here, sign-mask words) are issued first, unconditionally (rows outside the tensor read
@@ -407,6 +432,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                         vv[3] = fmaxf(vv[3], 0.f);
                     }
                     *(f32x4*)dst = vv;
+                    out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(vv[0]), fabsf(vv[1]))), fmaxf(fabsf(vv[2]), fabsf(vv[3])));
                     if (flags & SPK_EPI_BNBWD) {
                         const f32x4 rw = rwv[kk];
                         f32x4 dz;
@@ -428,6 +454,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 }
             }
         }
+        if (a.out_amax) spk_wave_amax_commit(out_mx, a.out_amax);
         if (flags & SPK_EPI_STATS) {
 #pragma unroll
             for (int off = Q; off < 64; off <<= 1) {

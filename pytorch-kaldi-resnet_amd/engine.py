@@ -185,7 +185,8 @@ class Engine:
             evs = [bn.eval_coeffs() for bn in b.bns]
             if b.ds is not None:
                 ed = b.ds[1].eval_coeffs()
-                res, _ = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, epi_affine=(ed[0], ed[1]))
+                res, _ = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, epi_affine=(ed[0], ed[1]),
+                                      in_amax=a_amax if ops.split_for(1) == 3 else None)
             else:
                 res = a
             h, h_amax = a, a_amax
@@ -195,7 +196,7 @@ class Engine:
                 o_amax = take()
                 h, _ = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, epi_affine=(ev[0], ev[1]),
                                     epi_add=res if last else None, relu=True,
-                                    in_amax=h_amax if (f16 and c.k == 3) else None, out_amax=o_amax)
+                                    in_amax=h_amax if ops.split_for(c.k) == 3 else None, out_amax=o_amax)
                 h_amax = o_amax
             a, a_amax = h, h_amax
         return a
@@ -290,13 +291,14 @@ class Engine:
                 rec["in_amax"].append(in_slot)
                 raw_amax = take()
                 raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True,
-                                       in_amax=in_slot if (f16 and c.k == 3) else None, out_amax=raw_amax)
+                                       in_amax=in_slot if ops.split_for(c.k) == 3 else None, out_amax=raw_amax)
                 t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2])
                 raws.append(raw)
                 h, aff, h_amax = raw, (t4[2], t4[3]), raw_amax
             out_amax = take()
             if b.ds is not None:
-                rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True)
+                rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True,
+                                        in_amax=a_amax if ops.split_for(1) == 3 else None)
                 td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2])
                 out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True, mask=use_masks,
                                    amax_out=out_amax)
@@ -433,7 +435,7 @@ class Engine:
             in_aff = None if i == 0 else (b.bns[i - 1].t4[2], b.bns[i - 1].t4[3])
             hw = (inp.shape[1], inp.shape[2])
             act = out if last else None
-            f16 = amx is not None and c.k == 3            # this conv's data / weight gradients run with fp16 two-term operands
+            f16 = amx is not None and ops.split_for(c.k, True) == 3     # data / weight gradients with fp16 two-term operands
             # what this conv's data gradient must also do in its epilogue
             add_dz, bnb = False, None
             if i > 0:
@@ -485,12 +487,15 @@ class Engine:
         dx, part, dx_amax = g, g_part, g_amax
         if b.ds is not None:
             cd, bnd = b.ds
+            f16d = amx is not None and ops.split_for(1, True) == 3
+            drawd_amax = take() if f16d else None
             drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
-                                    MASK_NONE, draw_out=dz, accumulate=acc)
-            self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc)
+                                    MASK_NONE, draw_out=dz, accumulate=acc, amax_out=drawd_amax)
+            self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc, dy_amax=drawd_amax,
+                        x_amax=rec["in_amax"][0] if f16d else None)
             # the 1x1 gradient lands on top of the 3x3 one: the same slot ends up >= the absmax of the sum's final values
             ops.conv_dgrad(drawd, cd.wpk_t, cd.cin, 1, cd.stride, (x.shape[1], x.shape[2]), out=dx, accumulate=True,
-                           out_amax=dx_amax)
+                           in_amax=drawd_amax, out_amax=dx_amax)
             part = None
         return dx, part, dx_amax
 

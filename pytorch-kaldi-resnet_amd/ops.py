@@ -118,11 +118,17 @@ WS_MIN_TAPS = int(os.environ.get("SPK_WS_MIN_TAPS", "9"))
 WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
+SPLIT_1X1 = os.environ.get("SPK_SPLIT_1X1", "1") == "1"
+
+
 def split_for(ksize, bwd=False):
-    """operand mode of a convolution launch: 3x3 only (1x1 convolutions and the stem stay on fp32 operands)"""
-    if ksize != 3:
-        return 0
-    return SPLIT_BWD if (bwd and SPLIT_BWD is not None) else SPLIT
+    """operand mode of a convolution launch.  The bf16-term modes cover the 3x3 convolutions only (1x1 convolutions stay on
+    fp32 operands there); f16x3 also runs the 1x1 convolutions (Bottleneck blocks, downsample branches).  The stem (Cin = 1)
+    is a direct convolution in every mode."""
+    mode = SPLIT_BWD if (bwd and SPLIT_BWD is not None) else SPLIT
+    if ksize == 3:
+        return mode
+    return 3 if (mode == 3 and SPLIT_1X1 and ksize == 1) else 0
 
 
 def pack_conv_weight(w, transpose=False, out=None):
@@ -193,7 +199,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
     # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
     ws, WC = None, 1
-    if split in (6, 9) and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
+    if split and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
         ws = WS_FORCE or tiling.ws_tile(*key)
     if ws is not None:
         TH, TW, MT, NT, WC = ws
@@ -365,7 +371,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             else:
                 out.zero_()
         _conv_launch(dy, wpk_t, out, Cin, [(0, 0, 0)], 1, 2, 0, 0, (IH + 1) // 2, (IW + 1) // 2, None, None, out, False,
-                     False, out_amax=out_amax)
+                     False, split=split_for(1, True), in_amax=in_amax, out_amax=out_amax)
         return out
     for cy in range(2):
         for cx in range(2):
@@ -437,8 +443,8 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_split_kernel<%d,%d,%d,%d>" % (
-             4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
+         label=("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
+             ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())

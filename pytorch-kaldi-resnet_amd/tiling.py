@@ -60,7 +60,7 @@ def conv_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_config=3, spl
         for NT in (1, 2, 4):
             if Cout % (32 * NT) or MT * NT > 8 or (MT * NT == 8 and MT == 4):
                 continue
-            if split and (MT, NT) not in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2), (1, 4)):
+            if split and (MT, NT) not in ((1, 1), (2, 1), (3, 1), (4, 1), (1, 2), (2, 2), (3, 2), (1, 4)):
                 continue
             best = []
             for TH in range(1, min(OH, cap) + 1):
@@ -99,10 +99,10 @@ WS_LDS_BYTES = 160 * 1024
 WS_MIN_COUT = int(_os.environ.get("SPK_WS_MIN_COUT", "64"))
 
 
-def ws_lds_bytes(TH, TW, IS, kspan_y, kspan_x, NT):
+def ws_lds_bytes(TH, TW, IS, kspan_y, kspan_x, NT, pix_bytes=None):
     """two ring slots of the halo tile + one epilogue slab per consumer wave (spk_conv_ws_lds_bytes)"""
     halo = ((TH - 1) * IS + kspan_y) * ((TW - 1) * IS + kspan_x)
-    return 2 * halo * SPLIT_PIX_BYTES + 4 * 32 * (NT * 32 + 4) * 4 + 128
+    return 2 * halo * (pix_bytes or SPLIT_PIX_BYTES) + 4 * 32 * (NT * 32 + 4) * 4 + 128
 
 
 def ws_candidates(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, per_layout=4):

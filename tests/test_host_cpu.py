@@ -299,15 +299,16 @@ def test_tile_lookup_by_mode_and_operand_mode(monkeypatch):
         k, st = key[4], key[5]
         assert TH * TW <= tiling.WGRAD_MAX_TILE[WN] and ((TH - 1) * st + k) * ((TW - 1) * st + k) <= tiling.WGRAD_MAX_HALO and TW % 2 == 0
     for c in tiling.conv_candidates(20, 75, 1, 3, 3, 9, 128, split=6):
-        assert (c[2], c[3]) in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2), (1, 4))
+        assert (c[2], c[3]) in ((1, 1), (2, 1), (3, 1), (4, 1), (1, 2), (2, 2), (3, 2), (1, 4))
 
 
 def test_operand_modes_are_declared():
     from pytorch_kaldi_resnet_amd import ops
     assert ops.MFMA_MODES == {"f32": 0, "bf16x6": 6, "bf16x9": 9, "f16x3": 3}
     assert ops.SPLIT in ops.MFMA_MODES.values()
-    assert ops.split_for(1) == 0 and ops.split_for(3) == ops.SPLIT      # 1x1 convolutions always use fp32 operands
-    assert ops.split_for(1, bwd=True) == 0 and ops.split_for(3, bwd=True) == (ops.SPLIT if ops.SPLIT_BWD is None else ops.SPLIT_BWD)
+    # 1x1 convolutions use fp32 operands in the bf16-term modes and the fp16 terms in f16x3
+    assert ops.split_for(1) == (3 if ops.SPLIT == 3 and ops.SPLIT_1X1 else 0) and ops.split_for(3) == ops.SPLIT
+    assert ops.split_for(3, bwd=True) == (ops.SPLIT if ops.SPLIT_BWD is None else ops.SPLIT_BWD)
     import torch
     w = torch.zeros(64, 32, 3, 3)
     old = (ops.SPLIT, ops.SPLIT_BWD)

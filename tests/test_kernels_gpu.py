@@ -188,7 +188,8 @@ def test_conv_fwd_dgrad_wgrad(ops, case, mfma_mode):
 
 @pytest.mark.parametrize("layout", [(2, 1, 1), (4, 1, 1), (3, 2, 1), (3, 1, 2), (6, 1, 2), (3, 1, 4), (6, 1, 4)])
 @pytest.mark.parametrize("shape", [(2, 128, 11, 23, 1), (3, 128, 20, 27, 2)])
-def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape):
+@pytest.mark.parametrize("wsmode", [6, 3])
+def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape, wsmode):
     """csrc/conv_ws_kernel.h (producer / consumer waves, persistent blocks, LDS ring) against conv_mfma_kernel on ragged
     maps - tiles that overhang both edges, more tiles than blocks and fewer: forward (stride 1 and 2, fused input
     BN+ReLU, BN statistics), plain data gradient with shortcut add, and the fused BatchNorm-backward data gradient with
@@ -197,7 +198,7 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape):
     MT, NT, WC = layout
     B, C, H, Wd, stride = shape
     old = (ops.SPLIT, ops.WS_CONV, ops.WS_FORCE)
-    ops.SPLIT = 6
+    ops.SPLIT = wsmode
     try:
         tile = (5, 12, MT, NT, WC)       # 60 pixels: fits the smallest layout (96), leaves every layout's padding rows idle
         torch.manual_seed(7)
