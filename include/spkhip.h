@@ -46,15 +46,17 @@ const char* spk_last_error(void);
  * [tap][K/8][N/32][64][4]; transpose = 0 for the forward conv (K = Cin), 1 for its data gradient (K = Cout). */
 int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose, void* stream);
 /* the same weights for the split operand modes of spk_conv_mfma: split = 6 or 9: every weight as three bf16 terms whose sum
- * is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight; split = 3: w * 2^12 as two fp16 terms
- * (saturated), the same order with two terms = 4 bytes per weight */
+ * is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight; split = 3: a 16-byte header (word 0 = float
+ * bits of max|w|) followed by w * sigma as two fp16 terms in the same order (4 bytes per weight), sigma = the power of two
+ * that puts max|w| in [2^8, 2^9) - spk_conv_mfma reads the header and derives the same sigma */
 int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, int split,
                                void* stream);
 /* every convolution of the network in one launch: `jobs` is a device array of njobs 48-byte entries
  * { const float* w; void* wpk; int Cout, Cin, KH*KW, transpose, split, total = Cout*Cin*KH*KW, block0, pad; } ordered by
  * block0 (first 256-thread block of the job; total_blocks = sum of ceil(total/256)).  spk_pack_job_bytes() = 48. */
 int spk_pack_job_bytes(void);
-int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, void* stream);
+int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, int has_f16 /* the table holds split = 3
+                                  jobs: their absmax headers are refreshed first */, void* stream);
 
 /* Implicit-GEMM convolution described by a tap table; replaces F.conv2d forward (scripts/model.py:51,56,
  * 118,122,126,58-59) and, with a transposed pack and mirrored taps, its data gradient (autograd of the same,
@@ -70,10 +72,10 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * three bf16 terms while staged / packed (wpk from spk_pack_conv_weight_split) and the 6 most significant (or all 9) cross
  * terms multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - inputs, outputs and measured accuracy are fp32
  * (planes are then 16 channels: Cin % (16*kc) == 0).
- * split = 3 ("f16x3"): operands as two fp16 terms of value * sigma, sigma a power of two (weights: 2^12 at pack time;
+ * split = 3 ("f16x3"): operands as two fp16 terms of value * sigma, sigma a power of two (weights: from max|w| at pack time;
  * staged input: 2^6 when in_amax is NULL - activations - else 2^(8 - exponent) of the float whose bits *in_amax holds,
  * the tensor's absmax or an upper estimate of it: gradients), three cross products on v_mfma_f32_32x32x16_f16, fp32
- * accumulation, accumulators scaled back by 1/(sigma_in * 2^12).  Measured accuracy = the fp32 instruction's
+ * accumulation, accumulators scaled back by 1/(sigma_in * sigma_w).  Measured accuracy = the fp32 instruction's
  * (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the launch atomically maxes the float
  * bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume those tensors. */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
@@ -127,7 +129,11 @@ int spk_bn_stats_partial(const float* x, float* partial /*[blocks][C][2]*/, long
 size_t spk_bn_finalize_workspace(int nblk, int C);
 int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* invstd,
-                    float* scale, float* shift, float momentum, float eps, double* ws, void* stream);
+                    float* scale, float* shift, float momentum, float eps, double* ws,
+                    const unsigned* amax_in, unsigned* est_out /* optional (f16x3 hand-off): *est_out = atomicMax over channels
+                    of bits(|scale_c| * A + |shift_c|), A = the float in *amax_in = absmax of the normalised tensor: an upper
+                    bound of |relu(bn(raw))|, the operand scale input of the convolution that applies this BN while staging */,
+                    void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int C, float eps, void* stream);
@@ -142,7 +148,9 @@ int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
                       void* stream);
 int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* invstd,
-                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws, void* stream);
+                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws,
+                        const unsigned* amax_in, unsigned* est_out /* optional: the spk_bnbwd_estimate value, per channel, by
+                        atomicMax - saves that launch */, void* stream);
 int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,
                      int C, int mask_mode, unsigned* amax_out /* optional: atomicMax of the float bits of |draw| */,

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ 
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ nbt, float* __restrict__ mean_out,
                                                           float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float momentum, float eps) {
+                                                          float* __restrict__ shift, float momentum, float eps,
+                                                          const unsigned* __restrict__ amax_in, unsigned* __restrict__ est_out) {
     __shared__ double red[8][32][2];
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
@@ -140,8 +141,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ 
         const float sc = g * invstd;
         mean_out[ch] = (float)mean;
         invstd_out[ch] = invstd;
+        const float shv = b - (float)mean * sc;
         scale[ch] = sc;
-        shift[ch] = b - (float)mean * sc;
+        shift[ch] = shv;
+        // f16x3 hand-off: upper bound of |relu(raw * scale_c + shift_c)| for the convolution that applies this BatchNorm while
+        // staging, from A = absmax(raw) (complete: the producing convolution ran before this launch): the maximum over
+        // channels of |scale_c| A + |shift_c|, one atomicMax per channel lane that can raise the slot
+        if (est_out) {
+            const float e = fabsf(sc) * __uint_as_float(*amax_in) + fabsf(shv);
+            const unsigned bits = __float_as_uint(e);
+            if (bits > __hip_atomic_load(est_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(est_out, bits);
+        }
         if (running_mean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
             running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
@@ -158,20 +168,23 @@ extern "C" size_t spk_bn_finalize_workspace(int nblk, int C) {
 extern "C" int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
                                float* invstd, float* scale, float* shift, float momentum, float eps, double* ws,
-                               void* stream) {
+                               const unsigned* amax_in, unsigned* est_out, void* stream) {
     SPK_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift, "spk_bn_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_finalize: bad sizes");
     SPK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "spk_bn_finalize: running stats must come in pairs");
+    SPK_REQUIRE(!est_out || amax_in, "spk_bn_finalize: est_out needs amax_in");
     hipStream_t st = (hipStream_t)stream;
     if (spk_bn_finalize_workspace(nblk, C)) {
         SPK_REQUIRE(ws, "spk_bn_finalize: %d partial rows need the fp64 workspace", nblk);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
         SPK_LAUNCH_CHECK("spk_bn_finalize(fold)");
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
-                           gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps);
+                           gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps,
+                           amax_in, est_out);
     } else {
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
-                           beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps);
+                           beta, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, momentum, eps, amax_in,
+                           est_out);
     }
     SPK_LAUNCH_CHECK("spk_bn_finalize");
     return 0;
@@ -340,7 +353,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restrict__ partial, int nblk, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef, int accumulate) {
+                                                              float* __restrict__ coef, int accumulate,
+                                                              const unsigned* __restrict__ amax_in, unsigned* __restrict__ est_out) {
     __shared__ double red[8][32][2];
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
@@ -356,15 +370,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
         }
         dbeta[ch] = accumulate ? dbeta[ch] + (float)s : (float)s;
         dgamma[ch] = accumulate ? dgamma[ch] + (float)ss : (float)ss;
-        coef[ch] = gamma[ch] * invstd[ch];
-        coef[C + ch] = (float)(s / count);
-        coef[2 * C + ch] = (float)(ss / count);
+        const float k1 = gamma[ch] * invstd[ch], m1 = (float)(s / count), m2 = (float)(ss / count);
+        coef[ch] = k1;
+        coef[C + ch] = m1;
+        coef[2 * C + ch] = m2;
+        // f16x3 hand-off: upper estimate of the values k1 (dz - m1 - xhat m2) the fused data gradient will stage (see
+        // spk_bnbwd_estimate), maximum over channels by atomicMax
+        if (est_out) {
+            const float e = SPK_F16_EST_HEADROOM * fabsf(k1) * (__uint_as_float(*amax_in) + fabsf(m1) + 8.f * fabsf(m2));
+            const unsigned bits = __float_as_uint(e);
+            if (bits > __hip_atomic_load(est_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(est_out, bits);
+        }
     }
 }
 
 extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate,
-                                   double* ws, void* stream) {
+                                   double* ws, const unsigned* amax_in, unsigned* est_out, void* stream) {
     SPK_REQUIRE(partial && gamma && invstd && dgamma && dbeta && coef, "spk_bn_bwd_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_bwd_finalize: bad sizes");
     hipStream_t st = (hipStream_t)stream;
@@ -373,10 +395,10 @@ extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
         SPK_LAUNCH_CHECK("spk_bn_bwd_finalize(fold)");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
-                           gamma, invstd, dgamma, dbeta, coef, accumulate);
+                           gamma, invstd, dgamma, dbeta, coef, accumulate, amax_in, est_out);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
-                           invstd, dgamma, dbeta, coef, accumulate);
+                           invstd, dgamma, dbeta, coef, accumulate, amax_in, est_out);
     }
     SPK_LAUNCH_CHECK("spk_bn_bwd_finalize");
     return 0;
@@ -444,14 +466,15 @@ extern "C" int spk_absmax(const float* x, unsigned* slot, long long n, void* str
 
 // Upper estimate of max |k1 (dz - m1 - xhat m2)| - the values a fused BatchNorm-backward data gradient stages - from the
 // coefficient rows [k1, m1, m2][C] and A = absmax of the incoming gradient (|dz| <= A): max_c |k1_c| (A + |m1_c| + 8 |m2_c|).
-// |xhat| <= 8 is a heuristic (values beyond it saturate gracefully: the staged fp16 terms are clamped), the operand scale
-// derived from the estimate leaves 2^7 of headroom on top.  *est = float bits (plain store: one estimate per launch).
+// |xhat| <= 8 is a heuristic, so the estimate is multiplied by SPK_F16_EST_HEADROOM (2^6): values up to 64x beyond it still
+// fit the fp16 range, anything larger saturates gracefully (the staged terms are clamped).  *est = float bits (plain store: one estimate per launch).
 __global__ __launch_bounds__(256) void bnbwd_estimate_kernel(const float* __restrict__ coef, int C, const unsigned* __restrict__ amax_in,
                                                              unsigned* __restrict__ est) {
     __shared__ float red[4];
     const float A = __uint_as_float(*amax_in);
     float mx = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, fabsf(coef[c]) * (A + fabsf(coef[C + c]) + 8.f * fabsf(coef[2 * C + c])));
+    for (int c = threadIdx.x; c < C; c += 256)
+        mx = fmaxf(mx, SPK_F16_EST_HEADROOM * fabsf(coef[c]) * (A + fabsf(coef[C + c]) + 8.f * fabsf(coef[2 * C + c])));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;

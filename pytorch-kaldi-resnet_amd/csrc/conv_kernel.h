@@ -68,7 +68,8 @@ struct ConvArgs {
     int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
     // f16x3 operand mode (SPLIT == 3)
     const unsigned* in_amax;   // float bits of the staged tensor's absmax (or an upper estimate); NULL: static in_sigma
-    float in_sigma, w_sigma;   // static input scale (activations) and the weight scale the packed weights carry
+    float in_sigma;            // static input scale when in_amax is NULL
+    const unsigned* w_amax;    // header of the fp16-split packed weights: float bits of max|w| -> the weight scale
     unsigned* out_amax;        // optional: atomicMax of |stored output| (float bits) - the next consumer's in_amax
     unsigned* side_amax;       // optional (IN_BNBWD): atomicMax of |side_draw| - the weight gradient's dY scale
     int tap_boff[9];  // wave-specialised kernel: float offset of (tap, channel plane 0) in the bf16-split packed weights
@@ -85,10 +86,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // f16x3: input scale (a power of two) and the factor that takes the accumulators back to fp32 units
-    float sig = 1.f, inv_sig = 1.f;
+    // (two factors: the product of the scales may leave the fp32 range, each reciprocal is an exact power of two)
+    float sig = 1.f, inv_sig = 1.f, inv_wsig = 1.f;
     if constexpr (SPLIT == 3) {
         sig = a.in_amax ? spk_sigma_from_amax_bits(*a.in_amax) : a.in_sigma;
-        inv_sig = 1.f / (sig * a.w_sigma);       // exact: both are powers of two
+        inv_sig = 1.f / sig;
+        inv_wsig = 1.f / spk_sigma_from_amax_bits(*a.w_amax);
     }
     float side_mx = 0.f;
 
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig : acc[i][j][e];
+                slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
             }
         // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
 #pragma unroll

@@ -84,7 +84,11 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     a.in_raw = in_raw; a.in_act = in_act; a.in_bn4 = in_bn4; a.in_coef = in_coef; a.side_draw = side_draw; a.side_dz = side_dz;
     a.in_mask = in_mask; a.bn_mask = bn_mask; a.add_mask = add_mask;
     a.in_amax = in_amax; a.out_amax = out_amax; a.side_amax = side_amax;
-    a.in_sigma = SPK_F16_ACT_SIGMA; a.w_sigma = SPK_F16_W_SIGMA;
+    a.in_sigma = SPK_F16_ACT_SIGMA; a.w_amax = nullptr;
+    if (split == 3) {       // fp16-split packs start with a 16-byte header: the float bits of max|w|
+        a.w_amax = (const unsigned*)wpk;
+        a.wpk = wpk + 4;
+    }
 
     SPK_REQUIRE(!add_mask || ((flags & SPK_EPI_ADD) && Cout % 32 == 0), "spk_conv_mfma: add_mask needs EPI_ADD and Cout %% 32 == 0");
     SPK_REQUIRE(ips >= 1 && ips <= 4, "spk_conv_mfma: ips=%d", ips);

@@ -244,13 +244,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     }
     if (wk == 0) {
         float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
-        const float inv = SPLIT == 3 ? 1.f / (sig_x * sig_d) : 1.f;     // powers of two: exact
+        const float inv_x = 1.f / sig_x, inv_d = 1.f / sig_d;           // powers of two: exact; applied one after the other
+                                                                         // (their product may leave the fp32 range)
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = SPLIT == 3 ? acc[t][e] * inv : acc[t][e];
+                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = SPLIT == 3 ? acc[t][e] * inv_x * inv_d : acc[t][e];
             }
     }
 }

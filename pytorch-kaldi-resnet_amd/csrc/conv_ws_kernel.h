@@ -66,10 +66,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     };
     int k = 0;                                    // work-item counter of this block: ring slot = k & 1
     // f16x3: input scale (a power of two) and the factor that takes the accumulators back to fp32 units
-    float sig = 1.f, inv_sig = 1.f;
+    float sig = 1.f, inv_sig = 1.f, inv_wsig = 1.f;
     if constexpr (SPLIT == 3) {
         sig = a.in_amax ? spk_sigma_from_amax_bits(*a.in_amax) : a.in_sigma;
-        inv_sig = 1.f / (sig * a.w_sigma);
+        inv_sig = 1.f / sig;
+        inv_wsig = 1.f / spk_sigma_from_amax_bits(*a.w_amax);
     }
     // per-tap table in LDS, behind the ring and the epilogue slabs: [0..11] A-fragment offset of the tap inside a slot
     // (16-byte units), [16..27] float offset of the tap's weight fragments; entries 9..11 repeat tap 8 (harmless prefetches)
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig : acc[i][j][e];
+                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
                 }
             // All global loads of the m-tile's epilogue (shortcut gradient, raw conv output of the BatchNorm whose backward
             // statistics are reduced here, sign-mask words) are issued first, unconditionally (rows outside the tensor read

@@ -3,7 +3,9 @@
 //   fp32 operands : [tap][K/8][N/32][64 lanes][4 floats]      lane l: n = 32 nt + (l & 31), k = 8 g + 4 (l >> 5) + {0..3}
 //   bf16 split    : [tap][K/16][term 0..2][N/32][64 lanes][8 bf16]  lane l: n as above, k = 16 g + 8 (l >> 5) + {0..7};
 //                   term s of a weight is the s-th bf16 of its exact three-term split (w = t0 + t1 + t2)
-//   fp16 split    : the same order with two terms: w * SPK_F16_W_SIGMA = h0 + h1 (+ 2^-22 relative), saturated (split = 3)
+//   fp16 split    : (split = 3) a 16-byte header - word 0 = float bits of max|w| over the tensor - followed by the same order
+//                   with two terms: w * sigma = h0 + h1 (+ 2^-22 relative), sigma = the power of two that puts max|w| in
+//                   [2^8, 2^9) (spk_sigma_from_amax_bits: the convolution kernels derive the same sigma from the header)
 // spk_pack_conv_weights_batched packs every convolution of the network in ONE launch from a device-resident job table
 // (the weights change every step, so this runs once per step: 70 tiny launches become one).
 #include "spk_common.h"
@@ -25,7 +27,7 @@ static __device__ __forceinline__ void pack_f32_elem(const float* __restrict__ w
 
 template <int NTERM>
 static __device__ __forceinline__ void pack_split_elem(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout,
-                                                       int Cin, int KHW, int transpose, int idx) {
+                                                       int Cin, int KHW, int transpose, int idx, float sigma = 1.f) {
     const int K = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
     int i = idx;
     const int e = i & 7; i >>= 3;
@@ -40,7 +42,8 @@ static __device__ __forceinline__ void pack_split_elem(const float* __restrict__
     const size_t term = (size_t)(N >> 5) * 512;
     const size_t o = ((((size_t)t * (K >> 4) + g) * NTERM) * (N >> 5) + nt) * 512 + lane * 8 + e;
     if constexpr (NTERM == 2) {
-        x = fminf(fmaxf(x * SPK_F16_W_SIGMA, -65504.f), 65504.f);
+        wpk += 8;                                           // past the 16-byte header
+        x = fminf(fmaxf(x * sigma, -65504.f), 65504.f);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const _Float16 b = (_Float16)x;
@@ -67,8 +70,17 @@ __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, unsig
                                               int KHW, int transpose, int total, int split) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    if (split == 3) pack_split_elem<2>(w, wpk, Cout, Cin, KHW, transpose, idx);
+    if (split == 3) pack_split_elem<2>(w, wpk, Cout, Cin, KHW, transpose, idx, spk_sigma_from_amax_bits(*(const unsigned*)wpk));
     else pack_split_elem<3>(w, wpk, Cout, Cin, KHW, transpose, idx);
+}
+
+// header word 0 of an fp16-split pack <- float bits of max|w| (zeroed first; the tensor is a few 10^5 values)
+__global__ void pack_header_zero_kernel(unsigned* hdr) {
+    if (threadIdx.x < 4) hdr[threadIdx.x] = 0u;
+}
+__global__ void pack_header_amax_kernel(const float* __restrict__ w, unsigned* hdr, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    spk_wave_amax_commit(idx < total ? fabsf(w[idx]) : 0.f, hdr);
 }
 
 extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int transpose,
@@ -83,13 +95,18 @@ extern "C" int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Ci
     return 0;
 }
 
-// split: 6 / 9 -> three bf16 terms (numel * 6 bytes), 3 -> two fp16 terms (numel * 4 bytes)
+// split: 6 / 9 -> three bf16 terms (numel * 6 bytes), 3 -> 16-byte header + two fp16 terms (16 + numel * 4 bytes)
 extern "C" int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose,
                                           int split, void* stream) {
     SPK_REQUIRE(w && wpk, "spk_pack_conv_weight_split: null pointer");
     SPK_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "spk_pack_conv_weight_split: channels (%d,%d) must be multiples of 32", Cout, Cin);
     SPK_REQUIRE(KH * KW >= 1 && KH * KW <= 9, "spk_pack_conv_weight_split: kernel %dx%d unsupported", KH, KW);
     const int total = Cout * Cin * KH * KW;
+    if (split == 3) {
+        hipLaunchKernelGGL(pack_header_zero_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)wpk);
+        hipLaunchKernelGGL(pack_header_amax_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                           (unsigned*)wpk, total);
+    }
     hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3(spk_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (unsigned short*)wpk, Cout, Cin, KH * KW, transpose, total, split);
     SPK_LAUNCH_CHECK("spk_pack_conv_weight_split");
@@ -108,26 +125,54 @@ struct PackJob {
     int pad;
 };
 
-__global__ void pack_conv_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs) {
+static __device__ __forceinline__ int pack_job_of_block(const PackJob* __restrict__ jobs, int njobs, int b) {
     int lo = 0, hi = njobs - 1;
-    const int b = blockIdx.x;
     while (lo < hi) {                       // last job whose block0 <= b (uniform per block: scalar loads)
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].block0 <= b) lo = mid;
         else hi = mid - 1;
     }
-    const PackJob j = jobs[lo];
+    return lo;
+}
+
+// fp16-split jobs: header word 0 of the destination <- float bits of max|w| (two tiny pre-passes of the batched pack)
+__global__ void pack_headers_zero_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < njobs && jobs[i].split == 3) {
+        unsigned* h = (unsigned*)jobs[i].wpk;
+        h[0] = h[1] = h[2] = h[3] = 0u;
+    }
+}
+__global__ void pack_headers_amax_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const PackJob j = jobs[pack_job_of_block(jobs, njobs, blockIdx.x)];
+    if (j.split != 3) return;
+    const int idx = (blockIdx.x - j.block0) * 256 + threadIdx.x;
+    spk_wave_amax_commit(idx < j.total ? fabsf(j.w[idx]) : 0.f, (unsigned*)j.wpk);
+}
+
+__global__ void pack_conv_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const int b = blockIdx.x;
+    const PackJob j = jobs[pack_job_of_block(jobs, njobs, b)];
     const int idx = (b - j.block0) * 256 + threadIdx.x;
     if (idx >= j.total) return;
-    if (j.split == 3) pack_split_elem<2>(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
+    if (j.split == 3)
+        pack_split_elem<2>(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx,
+                           spk_sigma_from_amax_bits(*(const unsigned*)j.wpk));
     else if (j.split) pack_split_elem<3>(j.w, (unsigned short*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
     else pack_f32_elem(j.w, (float*)j.wpk, j.Cout, j.Cin, j.KHW, j.transpose, idx);
 }
 
 extern "C" int spk_pack_job_bytes(void) { return (int)sizeof(PackJob); }
 
-extern "C" int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, void* stream) {
+// has_f16: the table holds fp16-split jobs (split = 3): their absmax headers are refreshed first (two more launches)
+extern "C" int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks, int has_f16, void* stream) {
     SPK_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "spk_pack_conv_weights_batched: bad arguments");
+    if (has_f16) {
+        hipLaunchKernelGGL(pack_headers_zero_kernel, dim3(spk_ceil_div(njobs, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const PackJob*)jobs, njobs);
+        hipLaunchKernelGGL(pack_headers_amax_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                           njobs);
+    }
     hipLaunchKernelGGL(pack_conv_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs);
     SPK_LAUNCH_CHECK("spk_pack_conv_weights_batched");

@@ -53,12 +53,12 @@ class _BN:
         self.t4 = None      # train: [mean, invstd, scale, shift]
         self.e2 = None      # eval:  [scale, shift]
 
-    def finalize(self, partial, count):
+    def finalize(self, partial, count, amax_in=None, est_out=None):
         if self.t4 is None:
             self.t4 = torch.empty(4, self.c, device=partial.device, dtype=torch.float32)
         h = self.h
         ops.bn_finalize(partial, count, h.weight.data, h.bias.data, h.running_mean, h.running_var, h.num_batches_tracked,
-                        self.t4)
+                        self.t4, amax_in=amax_in, est_out=est_out)
         return self.t4
 
     def eval_coeffs(self):
@@ -283,18 +283,17 @@ class Engine:
             # or relu(bn(raw_{i-1})) recomputed in the staging - shared by the forward conv and its weight gradient
             rec = {"x": a, "xmask": amask, "in_amax": []}
             raws = []
-            h, aff, h_amax = a, None, a_amax
+            h, aff, h_amax = a, None, a_amax           # h_amax: slot describing the values the next conv stages from h
             for c, bn in zip(b.convs, b.bns):
-                in_slot = h_amax
-                if aff is not None and pool is not None:
-                    in_slot = ops.affine_estimate(aff[0], aff[1], h_amax, take())
-                rec["in_amax"].append(in_slot)
+                rec["in_amax"].append(h_amax)
                 raw_amax = take()
                 raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True,
-                                       in_amax=in_slot if ops.split_for(c.k) == 3 else None, out_amax=raw_amax)
-                t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2])
+                                       in_amax=h_amax if ops.split_for(c.k) == 3 else None, out_amax=raw_amax)
+                # the next conv stages relu(bn(raw)): its operand-scale bound comes out of the BatchNorm finalize
+                est = take()
+                t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2], amax_in=raw_amax, est_out=est)
                 raws.append(raw)
-                h, aff, h_amax = raw, (t4[2], t4[3]), raw_amax
+                h, aff, h_amax = raw, (t4[2], t4[3]), est
             out_amax = take()
             if b.ds is not None:
                 rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True,

@@ -22,7 +22,7 @@ _SIGS = {
     "spk_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_pack_conv_weight_split": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "spk_pack_job_bytes": [],
-    "spk_pack_conv_weights_batched": [_P, _I, _I, _P],
+    "spk_pack_conv_weights_batched": [_P, _I, _I, _I, _P],
     "spk_conv_mfma": [_P] * 21 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P, _P, _P, _P],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 16 + [_P, _P, _P],
     "spk_conv_wgrad_limits": [_I, _IP, _IP],
@@ -33,11 +33,11 @@ _SIGS = {
     "spk_stem_conv_wgrad": [_P] * 4 + [_I] * 4 + [_P],
     "spk_bn_stats_blocks": [_L, _I],
     "spk_bn_stats_partial": [_P, _P, _L, _I, _P],
-    "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P, _P],
+    "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P, _P, _P, _P],
     "spk_bn_eval_coeffs": [_P] * 6 + [_I, _F, _P],
     "spk_bn_apply": [_P] * 8 + [_L, _I, _I, _P, _P],
     "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P],
-    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P],
+    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P, _P, _P],
     "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P, _P],
     "spk_absmax": [_P, _P, _L, _P],
     "spk_bnbwd_estimate": [_P, _I, _P, _P, _P],

@@ -148,9 +148,10 @@ def pack_conv_weight(w, transpose=False, out=None):
 
 
 def packed_numel(w, bwd=False):
-    """floats of the packed form of an OIHW weight in the current operand mode (three bf16 terms = 6 bytes per weight,
-    two fp16 terms or fp32 = 4 bytes)."""
-    return w.numel() * 3 // 2 if split_for(w.shape[2], bwd) in (6, 9) else w.numel()
+    """floats of the packed form of an OIHW weight in the current operand mode (three bf16 terms = 6 bytes per weight;
+    fp32 = 4 bytes; two fp16 terms = 4 bytes + a 16-byte header with the tensor's absmax)."""
+    sp = split_for(w.shape[2], bwd)
+    return w.numel() * 3 // 2 if sp in (6, 9) else (w.numel() + 4 if sp == 3 else w.numel())
 
 
 class PackTable:
@@ -171,6 +172,7 @@ class PackTable:
             block0 += (w.numel() + 255) // 256
             self.key.append((w.data_ptr(), wpk.data_ptr(), transpose, split))
         self.njobs, self.blocks = len(jobs), block0
+        self.has_f16 = any(k[3] == 3 for k in self.key)
         self.table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
         self.launches = 0               # eager launches + launches recorded into a hipGraph
         self.launches_captured = 0
@@ -179,7 +181,8 @@ class PackTable:
         self.launches += 1
         if torch.cuda.is_current_stream_capturing():
             self.launches_captured += 1
-        call("spk_pack_conv_weights_batched", ptr(self.table), self.njobs, self.blocks, stream(), label="spk_pack_conv_weight")
+        call("spk_pack_conv_weights_batched", ptr(self.table), self.njobs, self.blocks, 1 if self.has_f16 else 0, stream(),
+             label="spk_pack_conv_weight")
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
@@ -493,12 +496,13 @@ def _ws64(device):
     return w
 
 
-def bn_finalize(partial, count, gamma, beta, running_mean, running_var, nbt, out4):
-    """out4: tensor [4][C] = (mean, invstd, scale, shift)."""
+def bn_finalize(partial, count, gamma, beta, running_mean, running_var, nbt, out4, amax_in=None, est_out=None):
+    """out4: tensor [4][C] = (mean, invstd, scale, shift).  amax_in + est_out (f16x3 mode): also the upper bound of
+    |relu(raw*scale+shift)| from the slot with absmax(raw) (the affine_estimate value, without its launch)."""
     C = gamma.numel()
     call("spk_bn_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
          ptr(running_var), ptr(nbt), ptr(out4[0]), ptr(out4[1]), ptr(out4[2]), ptr(out4[3]), BN_MOMENTUM, BN_EPS,
-         ptr(_ws64(partial.device)), stream())
+         ptr(_ws64(partial.device)), ptr(amax_in), ptr(est_out), stream())
 
 
 def bn_eval_coeffs(gamma, beta, rm, rv, out2):
@@ -536,7 +540,7 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     else:
         part, nblk = partial, partial.shape[0]
     call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
-         1 if accumulate else 0, ptr(_ws64(raw.device)), stream())
+         1 if accumulate else 0, ptr(_ws64(raw.device)), None, None, stream())
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
@@ -551,9 +555,8 @@ def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, ama
     C = gamma.numel()
     coef = torch.empty(3, C, device=gamma.device, dtype=torch.float32)
     call("spk_bn_bwd_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(bn4[1]), ptr(dgamma),
-         ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), stream())
-    if est_out is not None:
-        call("spk_bnbwd_estimate", ptr(coef), C, ptr(amax_in), ptr(est_out), stream())
+         ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), ptr(amax_in) if est_out is not None else None,
+         ptr(est_out), stream())
     return coef
 
 

@@ -313,10 +313,10 @@ def test_operand_modes_are_declared():
     w = torch.zeros(64, 32, 3, 3)
     old = (ops.SPLIT, ops.SPLIT_BWD)
     try:
-        for mode, n in (("f32", w.numel()), ("bf16x6", w.numel() * 3 // 2), ("f16x3", w.numel())):
+        for mode, n in (("f32", w.numel()), ("bf16x6", w.numel() * 3 // 2), ("f16x3", w.numel() + 4)):
             ops.SPLIT, ops.SPLIT_BWD = ops.MFMA_MODES[mode], None
-            assert ops.packed_numel(w) == n and ops.packed_numel(w, bwd=True) == n       # 4 / 6 / 4 bytes per weight
+            assert ops.packed_numel(w) == n and ops.packed_numel(w, bwd=True) == n       # 4 / 6 / 4 (+16 header) bytes per weight
         ops.SPLIT, ops.SPLIT_BWD = 3, 6       # forward on fp16 terms, gradients on bf16 terms: the two packs differ
-        assert ops.packed_numel(w) == w.numel() and ops.packed_numel(w, bwd=True) == w.numel() * 3 // 2
+        assert ops.packed_numel(w) == w.numel() + 4 and ops.packed_numel(w, bwd=True) == w.numel() * 3 // 2
     finally:
         ops.SPLIT, ops.SPLIT_BWD = old

@@ -341,10 +341,100 @@ def test_split_operands_are_as_accurate_as_fp32_operands(ops):
         finally:
             ops.SPLIT = old
         print(name, {k: ["%.2e" % e for e in v] for k, v in errs.items()})
-        for mode in ("bf16x6", "bf16x9"):
+        for mode in ("bf16x6", "bf16x9", "f16x3"):
             for e_split, e_f32 in zip(errs[mode], errs["f32"]):
                 assert e_split <= 3.0 * e_f32 + 1e-9 and e_split < 1e-6, (name, mode, errs)
         assert max(errs["f32"]) < 2e-5        # rms error relative to the rms of the exact result
+
+
+@pytest.mark.parametrize("case", ["tiny", "huge", "outlier", "zeros", "tiny_grad_big_act"])
+def test_split_operands_at_extreme_magnitudes(ops, case):
+    """Worst cases of the split operand modes - where a term could underflow (bf16's third term, the second fp16 term) or
+    overflow (fp16 tops out at 65504): magnitudes near the bottom and the top of the fp32 range, one outlier 10^6 times the
+    rest, all-zero tensors, 1e-12 gradients against O(10) activations.  f16x3 rescales every operand tensor by a power of
+    two from its absmax, so none of these may cost accuracy: per output element the error must stay within a few fp32
+    rounding steps of the exact result's scale, in every mode, for forward, data gradient and weight gradient; and the
+    maximum error (not only the rms) is bounded against the native fp32 instruction's."""
+    torch.manual_seed(11)
+    B, C, H, Wd = 2, 64, 9, 14
+    x = torch.relu(torch.randn(B, C, H, Wd) + 0.3)
+    w = torch.randn(C, C, 3, 3) * 0.04
+    dy = torch.randn(B, C, H, Wd)
+    if case == "tiny":
+        x, dy = x * 1e-14, dy * 1e-17          # (their products, 1e-31, still sit inside the fp32 range)
+    elif case == "huge":
+        x, w, dy = x * 1e15, w * 1e3, dy * 1e12
+    elif case == "outlier":           # 10^3 x the typical magnitude in every operand: elements down to 1 % of typical still
+        x[0, 3, 4, 5] = 1e3           # sit inside f16x3's 2^18 full-precision window below the tensor's absmax
+        dy[1, 7, 2, 2] = -1e3
+        w[5, 6, 1, 1] = 40.0
+    elif case == "zeros":
+        x, dy = x * 0, dy * 0
+    elif case == "tiny_grad_big_act":
+        x, dy = x * 20, dy * 1e-12
+    x64, w64, dy64 = (t.double().requires_grad_(True) for t in (x, w, dy))
+    ref = F.conv2d(x64, w64, None, 1, 1)
+    gx, gw = torch.autograd.grad(ref, [x64, w64], grad_outputs=dy64)
+    # |error| is judged against sum |a||b| of each output (what fp32 rounding of the terms is proportional to)
+    mag = [F.conv2d(x64.abs(), w64.abs(), None, 1, 1).detach(),
+           torch.autograd.grad(F.conv2d(x64, w64.abs(), None, 1, 1), [x64], grad_outputs=dy64.abs())[0],
+           torch.autograd.grad(F.conv2d(x64.abs(), w64, None, 1, 1), [w64], grad_outputs=dy64.abs())[0]]
+    worst = {}
+    old = ops.SPLIT
+    try:
+        for mode, split in ops.MFMA_MODES.items():
+            ops.SPLIT = split
+            wg = w.cuda()
+            out, _ = ops.conv_fwd(nhwc(x), ops.pack_conv_weight(wg), C, 3, 1)
+            dx = ops.conv_dgrad(nhwc(dy), ops.pack_conv_weight(wg, transpose=True), C, 3, 1, (H, Wd))
+            dw = torch.empty(C, C, 3, 3, device="cuda")
+            ops.conv_wgrad(nhwc(x), nhwc(dy), dw, 3, 1)
+            torch.cuda.synchronize()
+            res = []
+            for got, exact, m in ((nchw(out), ref, mag[0]), (nchw(dx), gx, mag[1]), (dw.cpu(), gw, mag[2])):
+                assert torch.isfinite(got).all(), (case, mode)
+                scale = float(m.max()) if float(m.max()) > 0 else 1.0
+                # per element against its own magnitude sum, with a floor of 1e-6 of the largest one (elements that are
+                # sums of nothing but vanishing terms are judged on the tensor's scale)
+                rel = (got.double() - exact.detach()).abs() / torch.clamp(m, min=1e-6 * scale)
+                res.append(float(rel.max()))
+            worst[mode] = res
+    finally:
+        ops.SPLIT = old
+    print(case, {k: ["%.2e" % e for e in v] for k, v in worst.items()})
+    for mode, res in worst.items():
+        for e, e32 in zip(res, worst["f32"]):
+            assert e < 2e-6, (case, mode, worst)                       # ~30 fp32 rounding steps of sum |a||b|, K = 576
+            assert e <= 4.0 * e32 + 2e-7, (case, mode, worst)          # and never far from the fp32 instruction itself
+
+
+def test_f16x3_precision_floor_below_the_scale_window(ops):
+    """The documented limit of the f16x3 mode (csrc/spk_common.h): operand scales are per TENSOR, so one element 10^7 times
+    the rest pushes the rest below amax * 2^-18, where the second fp16 term leaves the normal range and is lost (measured:
+    the matrix instruction does not keep fp16 subnormals): those elements are carried with 11 significant bits, i.e. an
+    absolute error of at most 2^-12 * amax * 2^-18 = amax * 2^-30 each.  The bf16 modes (fp32's exponent range) have no
+    such floor.  Asserted here: that floor holds (error of every output <= fp32-class relative part + K * amax_x * amax_w
+    * 2^-29), nothing overflows, and the outputs that involve the outlier itself stay fp32-accurate."""
+    torch.manual_seed(12)
+    B, C, H, Wd = 1, 64, 9, 14
+    x = torch.relu(torch.randn(B, C, H, Wd) + 0.3)
+    x[0, 3, 4, 5] = 3e7
+    w = torch.randn(C, C, 3, 3) * 0.04
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    old = ops.SPLIT
+    try:
+        ops.SPLIT = ops.MFMA_MODES["f16x3"]
+        out, _ = ops.conv_fwd(nhwc(x), ops.pack_conv_weight(w.cuda()), C, 3, 1)
+    finally:
+        ops.SPLIT = old
+    got = nchw(out).double()
+    assert torch.isfinite(got).all()
+    floor = 576 * float(x.abs().max()) * float(w.abs().max()) * 2.0 ** -29
+    err = (got - ref).abs()
+    assert bool((err <= 2e-6 * mag + floor).all()), float((err - 2e-6 * mag).max() / floor)
+    near = mag > 1e3                     # outputs whose sum contains the outlier
+    assert bool(near.any()) and float((err[near] / mag[near]).max()) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 13), (3, 80, 200), (1, 40, 37)])
