@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, FEAT, FRAMES, SPK = 256, 80, 300, 1211
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: dense bf16 matrix (no sparsity)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: dense bf16 / fp16 matrix (no sparsity)
+PEAK_HBM_GBS = 8000.0           # same table: HBM3E peak (6.3 TB/s is what a float4 copy achieves)
 
 
 def mfma_peak(kernel_label):
@@ -431,13 +432,15 @@ def main():
         torch.cuda.synchronize()
         overhead_ms = sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
         agg = {}
-        for name, flops, e0, e1 in recs:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
+        for name, flops, e0, e1, nbytes in recs:
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
             a[0] += max(e0.elapsed_time(e1) - overhead_ms, 1e-3) * 1e-3
             a[1] += flops
             a[2] += 1
-        name, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
+            a[3] += nbytes
+        name, (tsum, fsum, n, bsum) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fsum / tsum / 1e12
+        ach_gbs = bsum / tsum / 1e9
         # HBM traffic of that kernel: rocprofv3 cannot run inside this process, so this is the COMMITTED PMC pass of the
         # same command (profiles/pmc_traffic.json) - used only while the device sources still hash to what it measured
         traffic, traffic_note = None, "no committed PMC pass for this kernel"
@@ -456,15 +459,26 @@ def main():
                 traffic_note = ("committed PMC pass @ csrc %s: HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, separate "
                                 "rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json)" % pj["csrc_fingerprint"])
         peak, peak_note = mfma_peak(name)
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "peak_note": peak_note,
-                    "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note,
+        # The dominant kernel is priced against BOTH ceilings - matrix FLOP/s of its operand mode and HBM bytes/s of its
+        # algorithmic traffic (every tensor it must read or write, once) - and the larger fraction names the binding one.
+        f_mfma, f_hbm = ach / peak, ach_gbs / PEAK_HBM_GBS
+        hbm_bound = f_hbm >= f_mfma
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                    "achieved": round(ach_gbs if hbm_bound else ach, 2), "peak": PEAK_HBM_GBS if hbm_bound else round(peak, 1),
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(max(f_hbm, f_mfma), 4),
+                    "mfma": {"achieved_tflops": round(ach, 2), "peak_tflops": round(peak, 1), "frac": round(f_mfma, 4),
+                             "peak_note": peak_note, "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)},
+                    "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(f_hbm, 4),
+                            "algorithmic_bytes_per_launch": round(bsum / n),
+                            "note": "algorithmic bytes = inputs read once + outputs written once + every fused side stream "
+                                    "(shortcut, BatchNorm-backward raw / side gradient, masks) + packed weights"},
+                    "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
                     "event_bracket_overhead_us": round(overhead_ms * 1e3, 1),
                     "gflop_per_launch": round(fsum / n / 1e9, 3),
                     "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
                                         "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
+                                        "algorithmic_gbs": round(v[3] / v[0] / 1e9, 1) if v[3] else None,
                                         "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
     headline = args.arch == "resnet34" and nspk == SPK and var_x is None
     native = None

@@ -19,7 +19,8 @@ PROFILE = None
 _raw_call = call
 
 
-def call(name, *args, label=None, flops=0.0):   # noqa: F811  (instrumented wrapper around hip.call)
+def call(name, *args, label=None, flops=0.0, nbytes=0.0):   # noqa: F811  (instrumented wrapper around hip.call)
+    """nbytes: ALGORITHMIC bytes of the launch (every tensor it must read or write, once; no halo or re-read factors)"""
     if PROFILE is None:
         return _raw_call(name, *args)
     e0 = torch.cuda.Event(enable_timing=True)
@@ -27,7 +28,7 @@ def call(name, *args, label=None, flops=0.0):   # noqa: F811  (instrumented wrap
     e0.record()
     _raw_call(name, *args)
     e1.record()
-    PROFILE.append((label or name, flops, e0, e1))
+    PROFILE.append((label or name, flops, e0, e1, nbytes))
 
 
 def _iarr(v):
@@ -259,7 +260,15 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          stream(),
          label=("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
          else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
-         flops=2.0 * B * OH * OW * Cout * Cin * len(taps))
+         flops=2.0 * B * OH * OW * Cout * Cin * len(taps),
+         # algorithmic bytes: the input pixels this launch reads (all of them for a stride-1 / full-tap launch), the output it
+         # writes, and every fused side stream once: shortcut add, raw + side draw of the fused BatchNorm backward, raw of the
+         # BatchNorm whose backward statistics are reduced, the 1-bit masks; packed weights
+         nbytes=4.0 * (B * (IH // ips) * (IW // ips) * Cin * (min(1.0, len(taps) * OH * OW / max(1, (IH // ips) * (IW // ips))) if IS == 1 and OS > 1 else 1.0)
+                       + B * OH * OW * Cout * (1 + (1 if epi_add is not None else 0) + (1 if bn_bwd is not None else 0))
+                       + (2 * x.numel() if in_bnbwd is not None else 0)
+                       + (x.numel() / 32 if in_mask is not None else 0) + (B * OH * OW * Cout / 32) * ((bn_mask is not None) + (add_mask is not None))
+                       + wpk.numel()))
     return stats
 
 
@@ -449,7 +458,7 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
          label=("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
              ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
-         flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize)
+         flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize, nbytes=4.0 * (x.numel() + dy.numel() + nbytes / 4))
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw
 
