@@ -549,6 +549,8 @@ def main():
             "first_loss": round(first_loss, 4), "final_loss": round(lossv, 4),
             "loss_decreased_on_the_fixed_batch": bool(lossv < first_loss) if args.mode == "train" else None,
             "graph_replay_repacks_weights": repack_ok, "eer": eer,
+            "kernel_launches_per_step": (sum(v["launches_per_step"] for v in roofline["all_kernels"].values())
+                                         if roofline else None),
             "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native,
             "embedding_cosine_delta_vs_oracle": parity,
         }

@@ -63,9 +63,9 @@ struct ConvArgs {
     int halo_h, halo_w, min_dy, min_dx;
     unsigned halo_w_magic;   // ceil(2^32 / halo_w): p / halo_w == umulhi(p, magic) for p * halo_w < 2^32
     int ntaps, ncg, nblocks, flags;
-    int tap_off[9];   // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
-    int tap_w[9];     // weight tap index
-    int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
+    int tap_off[18];  // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
+    int tap_w[18];    // weight tap index
+    int tap_g[18];    // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
     // f16x3 operand mode (SPLIT == 3)
     const unsigned* in_amax;   // float bits of the staged tensor's absmax (or an upper estimate); NULL: static in_sigma
     float in_sigma;            // static input scale when in_amax is NULL

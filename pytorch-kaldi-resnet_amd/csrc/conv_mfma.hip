@@ -61,7 +61,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     const int ck = split ? SPK_SPLIT_CK : 32;                     // channels per staged plane
     const int nterm = split == 3 ? 2 : 3;
     const int lp4 = split ? (nterm * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
-    SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
+    SPK_REQUIRE(kc >= 1 && ntaps * kc <= 18 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
     SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT / ws_wc, "spk_conv_mfma: tile %dx%d exceeds %d pixels (MT=%d)", TH, TW, 128 * MT / ws_wc, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
     SPK_REQUIRE((OH - 1) * OS + ooy < OHf && (OW - 1) * OS + oox < OWf, "spk_conv_mfma: logical grid exceeds the output tensor");

@@ -144,10 +144,20 @@ __global__ void pack_headers_zero_kernel(const PackJob* __restrict__ jobs, int n
     }
 }
 __global__ void pack_headers_amax_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ float red[4];
     const PackJob j = jobs[pack_job_of_block(jobs, njobs, blockIdx.x)];
     if (j.split != 3) return;
     const int idx = (blockIdx.x - j.block0) * 256 + threadIdx.x;
-    spk_wave_amax_commit(idx < j.total ? fabsf(j.w[idx]) : 0.f, (unsigned*)j.wpk);
+    float v = idx < j.total ? fabsf(j.w[idx]) : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {          // one look at the slot (and at most one atomic) per block
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        unsigned* dst = (unsigned*)j.wpk;
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
 }
 
 __global__ void pack_conv_weights_batched_kernel(const PackJob* __restrict__ jobs, int njobs) {

@@ -110,16 +110,23 @@ SPLIT = MFMA_MODES[os.environ.get("SPK_MFMA", "f16x3")]
 SPLIT_BWD = MFMA_MODES[os.environ["SPK_MFMA_BWD"]] if os.environ.get("SPK_MFMA_BWD") else None
 
 
-# wave-specialised (producer / consumer, persistent) convolution kernel, csrc/conv_ws_kernel.h: opt-in (SPK_CONV_WS=1).
-# Measured on MI355X: +5..18 % per launch on fresh random operands (tools/ws_check.py), but no gain inside the training
-# step (bench.py: 78.3 ms with it on the 64..256-channel layers, 77.6 ms without) - the step is power-limited, the
-# matrix pipe is ~65 % busy at a 1.9 GHz clock either way - so conv_mfma_kernel stays the default.
-WS_CONV = os.environ.get("SPK_CONV_WS", "0") == "1"
+# wave-specialised (producer / consumer, persistent) convolution kernel, csrc/conv_ws_kernel.h.  SPK_CONV_WS = "0" never,
+# "1" every eligible 3x3 launch, "auto" (default) only where it wins INSIDE the training step on MI355X (per-layer
+# in-step times, profiles/r02_ws_instep.log): the data-gradient launches with the fused BN backward on >= 128 output
+# channels in the f16x3 mode (0.576 -> 0.552 ms and 0.466 -> 0.413 ms per launch; those kernels keep the matrix pipe only
+# ~25 % busy, so hiding the staging behind it pays).  Everywhere else conv_mfma_kernel is as fast or faster in-step
+# (the 32/64-channel layers lose 10-20 % to the wave-specialised layout), and in the bf16x6 mode the step is power-limited
+# and the two kernels tie.
+WS_CONV = os.environ.get("SPK_CONV_WS", "auto")
+assert WS_CONV in ("0", "1", "auto"), "SPK_CONV_WS must be 0, 1 or auto"
+WS_AUTO_MIN_COUT = 128
 WS_MIN_TAPS = int(os.environ.get("SPK_WS_MIN_TAPS", "9"))
+LABEL_SHAPES = os.environ.get("SPK_LABEL_SHAPES", "0") == "1"      # diagnostic: per-layer lines in bench.py's all_kernels
 WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
 SPLIT_1X1 = os.environ.get("SPK_SPLIT_1X1", "1") == "1"
+KC3_MAX_CIN = int(os.environ.get("SPK_KC3_MAX_CIN", "0"))     # 3x3 split launches with Cin <= this stage two 16-channel planes per barrier
 
 
 def split_for(ksize, bwd=False):
@@ -203,7 +210,9 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
     # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
     ws, WC = None, 1
-    if split and WS_CONV and len(taps) >= WS_MIN_TAPS and ips == 1:
+    ws_on = WS_CONV == "1" or WS_FORCE is not None or (
+        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT)
+    if split and ws_on and len(taps) >= WS_MIN_TAPS and ips == 1:
         ws = WS_FORCE or tiling.ws_tile(*key)
     if ws is not None:
         TH, TW, MT, NT, WC = ws
@@ -215,6 +224,13 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
             if Cin % (32 * cand) == 0 and cand * halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD:
                 kc = cand
                 break
+    elif split and ws is None and 2 * len(taps) <= 18 and Cin % 32 == 0 and Cin <= KC3_MAX_CIN:
+        # 3x3 on split operands: a staged plane is 16 channels = half a 128-byte line of the fp32 tensor.  Two planes per
+        # barrier put both halves of every line into one staging phase (the second half is an L2 hit instead of a second
+        # trip to HBM once the L2 has been streamed through in between) and halve the barriers.
+        halo = ((TH - 1) * IS + key[3]) * ((TW - 1) * IS + key[4])
+        if 2 * halo * (80 if split == 3 else tiling.SPLIT_PIX_BYTES) <= tiling.LDS_HARD:
+            kc = 2
     flags = 0
     if ws is not None:
         flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
@@ -258,8 +274,9 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), B, IH, IW, Cin, OH, OW, OHf, OWf, Cout, IS, OS, ooy, oox, len(taps),
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
          stream(),
-         label=("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
-         else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split),
+         label=(("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
+                else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split)) + (
+             " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps),
          # algorithmic bytes: the input pixels this launch reads (all of them for a stride-1 / full-tap launch), the output it
          # writes, and every fused side stream once: shortcut add, raw + side draw of the fused BatchNorm backward, raw of the

@@ -53,7 +53,7 @@ for li, (C, H, W) in enumerate(dims):
     flops = 2.0 * B * H * W * C * C * 9
     res = {}
     for ws in (False, True):
-        ops.WS_CONV = ws
+        ops.WS_CONV = "1" if ws else "0"
         out, st = ops.conv_fwd(x, wpk, C, 3, 1, in_affine=(sc, sh), stats=True)
         t_f = timeit(lambda: ops.conv_fwd(x, wpk, C, 3, 1, in_affine=(sc, sh), stats=True, out=out), args.reps)
         # fused BatchNorm-backward data gradient with sign masks, shortcut add and BN-backward statistics in the epilogue
