@@ -63,9 +63,9 @@ struct ConvArgs {
     int halo_h, halo_w, min_dy, min_dx;
     unsigned halo_w_magic;   // ceil(2^32 / halo_w): p / halo_w == umulhi(p, magic) for p * halo_w < 2^32
     int ntaps, ncg, nblocks, flags;
-    int tap_off[18];  // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
-    int tap_w[18];    // weight tap index
-    int tap_g[18];    // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
+    int tap_off[9];   // LDS offset (16-byte units) of the (tap, channel plane) inside the staged tile
+    int tap_w[9];     // weight tap index
+    int tap_g[9];     // weight K-group offset of the channel plane (fp32: 4 groups of 8 channels per plane; split: 1 of 16)
     // f16x3 operand mode (SPLIT == 3)
     const unsigned* in_amax;   // float bits of the staged tensor's absmax (or an upper estimate); NULL: static in_sigma
     float in_sigma;            // static input scale when in_amax is NULL
@@ -111,6 +111,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int b = pt / a.tiles_y;
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * a.IS + a.min_dy, ix0 = ox0 * a.IS + a.min_dx;
+    // Staging addresses: image bases are scalars (64-bit, SALU), the per-thread part is a 32-bit element offset inside image b;
+    // a halo slot outside the image reads a pixel of the halo that is inside (and is zeroed before it reaches LDS).
+    const int sy = min(max(iy0, 0), a.IH - 1), sx = min(max(ix0, 0), a.IW - 1);
+    const unsigned pi_safe = (unsigned)(sy * a.IW + sx), pi_safe_p = (unsigned)((sy * a.IWp + sx) * a.ips);
+    const float* img_in_p = a.in + (size_t)b * a.IHp * a.IWp * a.Cin;
+    const size_t img_el = (size_t)b * a.IH * a.IW * a.Cin;
+    const float* img_in = a.in + img_el;
+    const float* img_raw = BNBWD ? a.in_raw + img_el : nullptr;
+    const float* img_act = (BNBWD && a.in_act) ? a.in_act + img_el : nullptr;
+    const unsigned* img_mask = (BNBWD && a.in_mask) ? a.in_mask + (size_t)b * a.IH * a.IW * (a.Cin >> 5) : nullptr;
+    float* img_draw = BNBWD ? a.side_draw + img_el : nullptr;
+    float* img_dz = (BNBWD && a.side_dz) ? a.side_dz + img_el : nullptr;
     const int npix_tile = a.TH * a.TW;
     const int n0 = cg * NT * 32;
     const int flags = a.flags;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     f32x4 v[U2], rw[U2], ac[U2];
                     unsigned mw[U2];
                     bool inb[U2], core[U2];
-                    size_t off[U2];
+                    unsigned off[U2];          // element offset inside image b (32-bit: the image bases are scalars)
 #pragma unroll
                     for (int u = 0; u < U2; ++u) {
                         int p = base + PPP * u;
@@ -197,12 +209,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         const int iy = iy0 + hy, ix = ix0 + hx;
                         inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
                         core[u] = inb[u] && iy >= oy0 && iy < oy0 + a.TH && ix >= ox0 && ix < ox0 + a.TW;
-                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                        off[u] = (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + c;
-                        v[u] = *(const f32x4*)(a.in + off[u]);
-                        rw[u] = *(const f32x4*)(a.in_raw + off[u]);
-                        if (a.in_mask) mw[u] = a.in_mask[(size_t)((b * a.IH + cy) * a.IW + cx) * (a.Cin >> 5) + (c >> 5)];
-                        else if (a.in_act) ac[u] = *(const f32x4*)(a.in_act + off[u]);
+                        const unsigned pi = inb[u] ? (unsigned)(iy * a.IW + ix) : pi_safe;      // pixel inside image b
+                        off[u] = pi * (unsigned)a.Cin + (unsigned)c;
+                        v[u] = *(const f32x4*)(img_in + off[u]);
+                        rw[u] = *(const f32x4*)(img_raw + off[u]);
+                        if (a.in_mask) mw[u] = img_mask[pi * (unsigned)(a.Cin >> 5) + (unsigned)(c >> 5)];
+                        else if (a.in_act) ac[u] = *(const f32x4*)(img_act + off[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < U2; ++u) {
@@ -222,8 +234,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         if (p < halo_pix) {
                             store_px(ldsp, p, w);
                             if (owner && core[u]) {
-                                *(f32x4*)(a.side_draw + off[u]) = w;
-                                if (a.side_dz) *(f32x4*)(a.side_dz + off[u]) = dz;
+                                *(f32x4*)(img_draw + off[u]) = w;
+                                if (a.side_dz) *(f32x4*)(img_dz + off[u]) = dz;
                                 side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                             }
                         }
@@ -248,8 +260,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                         const int hx = p - hy * a.halo_w;
                         const int iy = iy0 + hy, ix = ix0 + hx;
                         inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-                        const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                        v[u] = *(const f32x4*)(a.in + (size_t)((b * a.IHp + cy * a.ips) * a.IWp + cx * a.ips) * a.Cin + c);
+                        const unsigned pi = inb[u] ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
+                        v[u] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)c);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {

@@ -61,12 +61,13 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     const int ck = split ? SPK_SPLIT_CK : 32;                     // channels per staged plane
     const int nterm = split == 3 ? 2 : 3;
     const int lp4 = split ? (nterm * SPK_SPLIT_CK * 2 + 16) / 16 : 9;    // LDS pixel pitch in 16-byte units (ConvCfg<SPLIT>::LP4)
-    SPK_REQUIRE(kc >= 1 && ntaps * kc <= 18 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
+    SPK_REQUIRE(kc >= 1 && ntaps * kc <= 9 && Cin % (ck * kc) == 0, "spk_conv_mfma: kc=%d incompatible with ntaps=%d, Cin=%d", kc, ntaps, Cin);
     SPK_REQUIRE(TH >= 1 && TW >= 1 && TH * TW <= 128 * MT / ws_wc, "spk_conv_mfma: tile %dx%d exceeds %d pixels (MT=%d)", TH, TW, 128 * MT / ws_wc, MT);
     SPK_REQUIRE(IS >= 1 && OS >= 1 && ooy >= 0 && oox >= 0, "spk_conv_mfma: bad strides/offsets");
     SPK_REQUIRE((OH - 1) * OS + ooy < OHf && (OW - 1) * OS + oox < OWf, "spk_conv_mfma: logical grid exceeds the output tensor");
     SPK_REQUIRE((long long)B * OHf * OWf * Cout < 2147483647LL && (long long)B * IH * IW * Cin < 2147483647LL * 4,
                 "spk_conv_mfma: tensor too large for 32-bit element offsets");
+    SPK_REQUIRE((long long)IH * IW * Cin < 2147483647LL, "spk_conv_mfma: one image exceeds 32-bit element offsets");
     SPK_REQUIRE(!(flags & SPK_IN_AFFINE_RELU) || (in_scale && in_shift), "spk_conv_mfma: IN_AFFINE_RELU needs scale/shift");
     SPK_REQUIRE(!(flags & SPK_EPI_AFFINE) || (epi_scale && epi_shift), "spk_conv_mfma: EPI_AFFINE needs scale/shift");
     SPK_REQUIRE(!(flags & SPK_EPI_ADD) || epi_add, "spk_conv_mfma: EPI_ADD needs epi_add");

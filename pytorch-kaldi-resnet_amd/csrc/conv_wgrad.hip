@@ -15,6 +15,7 @@
 
 // bf16-split instantiations live in conv_wgrad_split.hip
 int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st);
+int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);        // conv_wgrad_split.hip: producer / consumer form
 
 template <int NTAPS, int WK, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -280,6 +281,8 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     SPK_REQUIRE(!(flags & SPK_IN_AFFINE_RELU) || (in_scale && in_shift), "spk_conv_wgrad: IN_AFFINE_RELU needs scale/shift");
     SPK_REQUIRE((long long)B * IH * IW * Cin < 2147483647LL * 4 && (long long)B * OH * OW * Cout < 2147483647LL * 4,
                 "spk_conv_wgrad: tensor too large");
+    SPK_REQUIRE((long long)IH * IW * Cin * 4 < 4294967295LL && (long long)OH * OW * Cout * 4 < 4294967295LL,
+                "spk_conv_wgrad: one image exceeds 32-bit byte offsets");
     WgradArgs a;
     a.x = x; a.dy = dy; a.partial = partial; a.in_scale = in_scale; a.in_shift = in_shift;
     a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
@@ -299,6 +302,11 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
                 a.halo_h, a.halo_w, 32 * WGRAD_NX);
     SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
                 TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
+    if (flags & SPK_CONV_WS) {
+        SPK_REQUIRE(split == 3 && ksize == 3, "spk_conv_wgrad: the producer / consumer kernel exists for 3x3 in the f16x3 mode");
+        a.flags = flags & ~SPK_CONV_WS;
+        return spk_launch_wgrad_ws(a, WN, (hipStream_t)stream);
+    }
     if (split) return spk_launch_wgrad_split(a, WN, split, (hipStream_t)stream);
     const int ntaps = ksize * ksize;
     const int WK = 4 / WN;

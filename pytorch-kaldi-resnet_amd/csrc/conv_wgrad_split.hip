@@ -18,6 +18,11 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+#ifdef WG_ABL_NO_FRAG
+    s16x8 v = {1, 2, 3, 4, 5, 6, 7, 8};
+    asm volatile("" : "+v"(v) : "v"(p0), "v"(p1));
+    return v;
+#endif
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -66,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     f32x4 px[NX], pd[ND];
     unsigned inx = 0, ind = 0;
 
+    // Address arithmetic of the prefetch: the image base is a scalar (64-bit, SALU), the per-thread part a 32-bit byte offset
+    // inside the image; a slot outside the image reads the region's first output pixel instead (always inside) and is
+    // zeroed when published.  (The clamped 64-bit form cost ~26 VALU instructions per load, a quarter of the staging.)
+    const unsigned x_row = (unsigned)a.IW * a.Cin * 4u, x_px = (unsigned)a.Cin * 4u;
+    const unsigned d_row = (unsigned)a.OW * a.Cout * 4u, d_px = (unsigned)a.Cout * 4u;
+    const unsigned x_c = (unsigned)(ci0 + quad * 4) * 4u, d_c = (unsigned)(co0 + cq * 4) * 4u;
     auto prefetch = [&](int region) {
         int pt = region;
         const int tx = pt % a.tiles_x;
@@ -74,32 +85,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
         const int b = pt / a.tiles_y;
         const int oy0 = ty * a.TH, ox0 = tx * a.TW;
         const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
+        const char* xb = (const char*)(a.x + (size_t)b * a.IH * a.IW * a.Cin);
+        const char* db = (const char*)(a.dy + (size_t)b * a.OH * a.OW * a.Cout);
+        const unsigned x_safe = (unsigned)(oy0 * a.S) * x_row + (unsigned)(ox0 * a.S) * x_px + x_c;
+        const unsigned d_safe = (unsigned)oy0 * d_row + (unsigned)ox0 * d_px + d_c;
         inx = 0;
         ind = 0;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            int p = (tid >> 3) + 32 * u;
-            p = p < halo_pix ? p : halo_pix - 1;
+            const int p = (tid >> 3) + 32 * u;
             const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
             const int hx = p - hy * a.halo_w;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) inx |= 1u << u;
-            const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-            px[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
+            const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW && p < halo_pix;
+            if (ok) inx |= 1u << u;
+            const unsigned off = ok ? (unsigned)iy * x_row + (unsigned)ix * x_px + x_c : x_safe;
+#ifdef WG_ABL_NO_PREFETCH
+            px[u] = (f32x4){(float)off, 0.f, 1.f, 2.f};
+#else
+            px[u] = *(const f32x4*)(xb + off);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
-            const int p0 = tid / QPP + PSTEP * u;
-            const int p = p0 < npix ? p0 : npix - 1;
+            const int p = tid / QPP + PSTEP * u;
             const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
             const int lx = p - ly * a.TW;
             const int oy = oy0 + ly, ox = ox0 + lx;
-            if (p0 < npix && oy < a.OH && ox < a.OW) ind |= 1u << u;
-            const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
-            pd[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+            const bool ok = p < npix && oy < a.OH && ox < a.OW;
+            if (ok) ind |= 1u << u;
+            const unsigned off = ok ? (unsigned)oy * d_row + (unsigned)ox * d_px + d_c : d_safe;
+#ifdef WG_ABL_NO_PREFETCH
+            pd[u] = (f32x4){(float)off, 0.f, 1.f, 2.f};
+#else
+            pd[u] = *(const f32x4*)(db + off);
+#endif
         }
     };
     auto publish = [&]() {      // registers -> three bf16 terms in LDS (zero outside the image / tile; fused BN+ReLU on X)
+#ifdef WG_ABL_NO_PUBLISH
+        if (a.flags != 12345) return;
+#endif
         // the BN coefficients are re-read here (L1-resident) rather than held in registers across the MFMA loop
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (flags & SPK_IN_AFFINE_RELU) {
@@ -162,6 +188,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     const int col_off = (g16 & 1) * 32 + p4 * 8;
 
     auto mma = [&](f32x16& c, const s16x8* af, const s16x8* bf) {
+#ifdef WG_ABL_NO_MMA
+        asm volatile("" : "+v"(c) : "v"(af[0]), "v"(bf[0]), "v"(af[1]), "v"(bf[1]));
+        return;
+#endif
 #pragma unroll
         for (int sum = (SPLIT == 9 ? 4 : (SPLIT == 6 ? 2 : 1)); sum >= 0; --sum)
 #pragma unroll
@@ -185,7 +215,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
         __syncthreads();
         if (region + a.nsplit < a.nregions) prefetch(region + a.nsplit);
 
+#ifdef WG_ABL_NO_KLOOP
+        for (int j = wk; j < (a.flags == 12345 ? nsteps_all : 0); j += WK) {
+#else
         for (int j = wk; j < nsteps_all; j += WK) {
+#endif
             int xa[2], da[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -254,6 +288,262 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
                 slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = SPLIT == 3 ? acc[t][e] * inv_x * inv_d : acc[t][e];
             }
     }
+}
+
+
+// ---- producer / consumer form (f16x3 operands) ---------------------------------------------------------------------------
+// Measured on MI355X (tools/wg_abl.sh, 128-channel 20x75 layer): the kernel above takes 0.43 ms, of which the K loop alone
+// (fragment reads + MFMAs) is 0.28 ms and the staging alone (address arithmetic, loads, fp16 split, LDS writes, barriers)
+// 0.26 ms - each wave does one after the other and the two resident blocks of a CU drift into the same phase, so the
+// matrix pipe is busy 39 % of the time.  Here a block has eight waves: waves 0-3 only run the K loop, waves 4-7 only stage
+// the NEXT region into the other half of a two-slot LDS ring; one barrier per region hands a slot over in both directions
+// (slot i & 1 is published before barrier i and read after it; the producers overwrite it after barrier i + 1, which the
+// consumers reach only when they are done reading).  Every SIMD holds one wave of each kind, so the VALU / memory work of
+// the staging runs under the MFMAs of the same SIMD.  Same MFMA order per accumulator as the kernel above: bit-identical slabs.
+template <int NTAPS, int WK, int WN, int NX>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    constexpr int KS = NTAPS == 9 ? 3 : 1;
+    constexpr int PX = 192;
+    constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);
+    const int tid = threadIdx.x & 255, lane = tid & 63;       // index within the role group (consumers / producers)
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int h = lane >> 5;
+    const int wk = wave / WN, wn = wave % WN;
+    const int ci0 = blockIdx.y * 32;
+    const int co0 = blockIdx.z * (32 * WN);
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int npix = a.TH * a.TW;
+    const int nsteps_all = (npix + 15) >> 4;
+    const int npix_pad = nsteps_all << 4;
+    const int slot_bytes = halo_pix * PX + npix_pad * PD;
+    const int flags = a.flags;
+    const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
+    const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
+    const int nmine = (a.nregions - (int)blockIdx.x + a.nsplit - 1) / a.nsplit;     // regions of this block (>= 1)
+
+    f32x16 acc[NTAPS];
+    if (producer) {
+        // ---- producers: global -> registers -> (BN + ReLU, zero padding, fp16 split) -> LDS slot ----
+        constexpr int ND = WGRAD_ND;
+        constexpr int QPP = WN * 8;
+        constexpr int PSTEP = 256 / QPP;
+        const int quad = tid & 7, cq = tid % QPP;
+        // two register sets: the loads of region i + 2 are issued as soon as region i has been published, so a region's
+        // global-memory latency has two region times to pass (one is not enough: the producers set the pace then)
+        f32x4 pxA[NX], pdA[ND], pxB[NX], pdB[ND];
+        unsigned inxA = 0, indA = 0, inxB = 0, indB = 0;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (flags & SPK_IN_AFFINE_RELU) {
+            sc = *(const f32x4*)(a.in_scale + ci0 + quad * 4);
+            sh = *(const f32x4*)(a.in_shift + ci0 + quad * 4);
+        }
+        auto prefetch = [&](f32x4 (&px)[NX], f32x4 (&pd)[ND], unsigned& inx, unsigned& ind, int region) {
+#ifdef WGWS_ABL_NO_L
+            if (a.flags != 12345) return;
+#endif
+            int pt = region;
+            const int tx = pt % a.tiles_x;
+            pt /= a.tiles_x;
+            const int ty = pt % a.tiles_y;
+            const int b = pt / a.tiles_y;
+            const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+            const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
+            inx = 0;
+            ind = 0;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                int p = (tid >> 3) + 32 * u;
+                p = p < halo_pix ? p : halo_pix - 1;
+                const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                const int hx = p - hy * a.halo_w;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) inx |= 1u << u;
+                const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
+                px[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int p0 = tid / QPP + PSTEP * u;
+                const int p = p0 < npix ? p0 : npix - 1;
+                const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+                const int lx = p - ly * a.TW;
+                const int oy = oy0 + ly, ox = ox0 + lx;
+                if (p0 < npix && oy < a.OH && ox < a.OW) ind |= 1u << u;
+                const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
+                pd[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+            }
+        };
+        auto publish = [&](const f32x4 (&px)[NX], const f32x4 (&pd)[ND], unsigned inx, unsigned ind, unsigned char* xs) {
+#ifdef WGWS_ABL_NO_P
+            if (a.flags != 12345) return;
+#endif
+            unsigned char* dys = xs + halo_pix * PX;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int p = (tid >> 3) + 32 * u;
+                f32x4 w = px[u];
+                if (flags & SPK_IN_AFFINE_RELU) {
+                    w = w * sc + sh;
+                    w[0] = fmaxf(w[0], 0.f);
+                    w[1] = fmaxf(w[1], 0.f);
+                    w[2] = fmaxf(w[2], 0.f);
+                    w[3] = fmaxf(w[3], 0.f);
+                }
+                if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p < halo_pix) {
+                    uint2* dst = (uint2*)(xs + p * PX) + quad;
+                    uint2 t0, t1;
+                    split2h(w, sig_x, t0, t1);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int p = tid / QPP + PSTEP * u;
+                const f32x4 w = ((ind >> u) & 1) ? pd[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p < npix_pad) {
+                    uint2* dst = (uint2*)(dys + p * PD + (cq >> 3) * 192) + (cq & 7);
+                    uint2 t0, t1;
+                    split2h(w, sig_d, t0, t1);
+                    dst[0] = t0;
+                    dst[8] = t1;
+                }
+            }
+        };
+        // region of this block's i-th turn: blockIdx.x + i * nsplit.  Barrier i: slot i & 1 is complete and the consumers
+        // are done with slot (i + 1) & 1.
+        const int r0 = blockIdx.x, rs = a.nsplit;
+        prefetch(pxA, pdA, inxA, indA, r0);
+        if (nmine > 1) prefetch(pxB, pdB, inxB, indB, r0 + rs);
+        for (int i = 0; i < nmine; i += 2) {
+            publish(pxA, pdA, inxA, indA, ldsb);
+            if (i + 2 < nmine) prefetch(pxA, pdA, inxA, indA, r0 + (i + 2) * rs);
+            __syncthreads();
+            if (i + 1 < nmine) {
+                publish(pxB, pdB, inxB, indB, ldsb + slot_bytes);
+                if (i + 3 < nmine) prefetch(pxB, pdB, inxB, indB, r0 + (i + 3) * rs);
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---- consumers: LDS slot -> transposing fragment reads -> MFMA ----
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+        const int col_off = (g16 & 1) * 32 + p4 * 8;
+        auto mma = [&](f32x16& c, const s16x8* af, const s16x8* bf) {
+            // h1*g2 + h2*g1 first, h1*g1 last (the order of conv_wgrad_split_kernel<.., 3, ..>)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1]), __builtin_bit_cast(f16x8, bf[0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), c, 0, 0, 0);
+        };
+        for (int i = 0; i < nmine; ++i) {
+            __syncthreads();       // barrier i
+            const unsigned char* xs = ldsb + (i & 1) * slot_bytes;
+            const unsigned char* dys = xs + halo_pix * PX;
+#ifdef WGWS_ABL_NO_K
+            for (int j = wk; j < (a.flags == 12345 ? nsteps_all : 0); j += WK) {
+#else
+            for (int j = wk; j < nsteps_all; j += WK) {
+#endif
+                int xa[2], da[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int pix = j * 16 + 8 * h + 4 * blk + q;
+                    const int pc = pix < npix ? pix : npix - 1;
+                    const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
+                    const int lx = pc - ly * a.TW;
+                    xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + col_off;
+                    da[blk] = pix * PD + wn * 192 + col_off;
+                }
+                s16x8 bf[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bf[s] = tr_read8(dys + da[0] + s * 64, dys + da[1] + s * 64);
+                s16x8 a0[2], a1[2];
+                auto load_a = [&](s16x8* af, int t) {
+                    const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s] = tr_read8(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+                };
+                load_a(a0, 0);
+#pragma unroll
+                for (int t = 0; t < NTAPS; t += 2) {
+                    if (t + 1 < NTAPS) load_a(a1, t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc[t], a0, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 2 < NTAPS) load_a(a0, t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < NTAPS) mma(acc[t + 1], a1, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // fold the WK pixel-splits into wk == 0 through LDS (fixed order), then one slab per block; every wave of the block
+    // takes part in the barriers
+    const int r = lane & 31;
+    if (WK > 1) {
+        float* red = (float*)ldsb;  // [WN][NTAPS][16][64]
+#pragma unroll 1
+        for (int src = 1; src < WK; ++src) {
+            __syncthreads();
+            if (!producer && wk == src) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((wn * NTAPS + t) * 16 + e) * 64 + lane] = acc[t][e];
+            }
+            __syncthreads();
+            if (!producer && wk == 0) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] += red[((wn * NTAPS + t) * 16 + e) * 64 + lane];
+            }
+        }
+    }
+    if (!producer && wk == 0) {
+        float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
+        const float inv_x = 1.f / sig_x, inv_d = 1.f / sig_d;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                slab[((size_t)t * a.Cin + ci0 + row) * a.Cout + co0 + wn * 32 + r] = acc[t][e] * inv_x * inv_d;
+            }
+    }
+}
+
+// LDS bytes of the producer / consumer kernel for a tile (0: does not fit)
+template <int NTAPS, int WK, int WN>
+static int launch_ws(const WgradArgs& a, hipStream_t st) {
+    const int npix_pad = ((a.TH * a.TW + 15) >> 4) << 4;
+    constexpr int PD = WN * 192 + (WN > 1 ? 64 : 0);
+    size_t lds_bytes = 2 * ((size_t)a.halo_h * a.halo_w * 192 + (size_t)npix_pad * PD);
+    const size_t red_bytes = (WK > 1) ? (size_t)WN * NTAPS * 16 * 64 * sizeof(float) : 0;
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(ws): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
+    dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
+    if (a.halo_h * a.halo_w <= 32 * 4) hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, WK, WN, 4>), grid, dim3(512), lds_bytes, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, WK, WN, WGRAD_NX>), grid, dim3(512), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_wgrad(ws)");
+    return 0;
+}
+
+int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st) {
+    SPK_REQUIRE(a.KW == 3, "spk_conv_wgrad(ws): 3x3 only");
+    if (WN == 1) return launch_ws<9, 4, 1>(a, st);
+    if (WN == 2) return launch_ws<9, 2, 2>(a, st);
+    return launch_ws<9, 1, 4>(a, st);
 }
 
 template <int NTAPS, int WK, int WN>

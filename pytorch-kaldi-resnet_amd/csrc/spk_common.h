@@ -65,21 +65,19 @@ static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uin
 // the 6-term bf16 split - the fp32 accumulation dominates - at half the matrix instructions of the latter.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define SPK_F16_ACT_SIGMA 64.0f       // fallback input scale when no absmax slot is given (the engine always gives one)
-static __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi, float& rlo, float& rhi) {
-    const _Float16 a = (_Float16)lo, b = (_Float16)hi;   // round to nearest even
-    rlo = lo - (float)a;                                  // exact in fp32
-    rhi = hi - (float)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-// w * sigma (saturated to the fp16 range) -> two fp16 quads (8 bytes each)
+// w * sigma (saturated to the fp16 range) -> two fp16 quads (8 bytes each).  Written on vectors so that the compiler
+// emits the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32: round to nearest even, two values per instruction): 18 VALU
+// instructions per float4 instead of 32 - the staging phases of the f16x3 kernels are VALU-bound on exactly this.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ void split2h(f32x4 w, float sigma, uint2& t0, uint2& t1) {
-    float u0 = fminf(fmaxf(w[0] * sigma, -65504.f), 65504.f), u1 = fminf(fmaxf(w[1] * sigma, -65504.f), 65504.f);
-    float u2 = fminf(fmaxf(w[2] * sigma, -65504.f), 65504.f), u3 = fminf(fmaxf(w[3] * sigma, -65504.f), 65504.f);
-    float r0, r1, r2, r3, q0, q1, q2, q3;
-    t0.x = pack_f16x2(u0, u1, r0, r1);
-    t0.y = pack_f16x2(u2, u3, r2, r3);
-    t1.x = pack_f16x2(r0, r1, q0, q1);
-    t1.y = pack_f16x2(r2, r3, q2, q3);
+    f32x4 u = w * sigma;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = __builtin_amdgcn_fmed3f(u[k], -65504.f, 65504.f);
+    const f16x4 a = __builtin_convertvector(u, f16x4);
+    const f32x4 r = u - __builtin_convertvector(a, f32x4);      // exact in fp32
+    const f16x4 b = __builtin_convertvector(r, f16x4);
+    t0 = __builtin_bit_cast(uint2, a);
+    t1 = __builtin_bit_cast(uint2, b);
 }
 // power-of-two scale from the bits of a tensor's absmax (or of an upper bound of it): amax * sigma in [2^14, 2^15), just
 // under the fp16 maximum (65504): every value >= amax * 2^-18 keeps both terms normal (22 significant bits); smaller ones

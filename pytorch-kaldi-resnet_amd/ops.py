@@ -120,13 +120,18 @@ SPLIT_BWD = MFMA_MODES[os.environ["SPK_MFMA_BWD"]] if os.environ.get("SPK_MFMA_B
 WS_CONV = os.environ.get("SPK_CONV_WS", "auto")
 assert WS_CONV in ("0", "1", "auto"), "SPK_CONV_WS must be 0, 1 or auto"
 WS_AUTO_MIN_COUT = 128
+# the same idea for the 3x3 weight gradients (f16x3 mode): eight-wave blocks, one per CU (conv_wgrad_ws_kernel).  Opt-in:
+# bit-identical, but 10-15 % SLOWER than conv_wgrad_split_kernel on every layer (tools/wg_abl3.sh, profiles/r02_wgrad_ablation.log:
+# producers alone 0.31 ms, consumers alone 0.28 ms, together 0.49 ms - the staging is VALU-bound and a SIMD does not run one
+# wave's VALU stream under another wave's MFMAs to any useful degree; two resident four-wave blocks interleave better).
+WS_WGRAD = os.environ.get("SPK_WGRAD_WS", "0") == "1"
+WS_WGRAD_BLOCKS = int(os.environ.get("SPK_WGRAD_WS_BLOCKS", "256"))
 WS_MIN_TAPS = int(os.environ.get("SPK_WS_MIN_TAPS", "9"))
 LABEL_SHAPES = os.environ.get("SPK_LABEL_SHAPES", "0") == "1"      # diagnostic: per-layer lines in bench.py's all_kernels
 WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
 SPLIT_1X1 = os.environ.get("SPK_SPLIT_1X1", "1") == "1"
-KC3_MAX_CIN = int(os.environ.get("SPK_KC3_MAX_CIN", "0"))     # 3x3 split launches with Cin <= this stage two 16-channel planes per barrier
 
 
 def split_for(ksize, bwd=False):
@@ -224,13 +229,6 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
             if Cin % (32 * cand) == 0 and cand * halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD:
                 kc = cand
                 break
-    elif split and ws is None and 2 * len(taps) <= 18 and Cin % 32 == 0 and Cin <= KC3_MAX_CIN:
-        # 3x3 on split operands: a staged plane is 16 channels = half a 128-byte line of the fp32 tensor.  Two planes per
-        # barrier put both halves of every line into one staging phase (the second half is an L2 hit instead of a second
-        # trip to HBM once the L2 has been streamed through in between) and halve the barriers.
-        halo = ((TH - 1) * IS + key[3]) * ((TW - 1) * IS + key[4])
-        if 2 * halo * (80 if split == 3 else tiling.SPLIT_PIX_BYTES) <= tiling.LDS_HARD:
-            kc = 2
     flags = 0
     if ws is not None:
         flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
@@ -464,15 +462,20 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
         _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
     TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split)
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
-    nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN))
+    # producer / consumer kernel (csrc/conv_wgrad_split.hip: conv_wgrad_ws_kernel): f16x3 3x3 launches whose two LDS slots fit
+    halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
+    wgws = (WS_WGRAD and split == 3 and ksize == 3
+            and 2 * (halo * 192 + -(-(TH * TW) // 16) * 16 * (WN * 192 + (64 if WN > 1 else 0))) <= 160 * 1024)
+    nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else None))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
     ws = _workspace(nbytes, x.device)
-    flags = IN_AFFINE_RELU if in_affine is not None else 0
+    flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0)
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
+         label=("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
+         else ("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
              ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize, nbytes=4.0 * (x.numel() + dy.numel() + nbytes / 4))

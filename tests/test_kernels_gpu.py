@@ -238,6 +238,39 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape, w
         ops.SPLIT, ops.WS_CONV, ops.WS_FORCE = old
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 32, 16, 40, 1), (2, 64, 128, 21, 37, 1), (2, 128, 128, 20, 75, 1), (4, 64, 128, 20, 31, 2),
+                                   (2, 256, 256, 10, 38, 1)])
+def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
+    """conv_wgrad_ws_kernel (eight waves: four stage the next region, four run the MFMAs; csrc/conv_wgrad_split.hip)
+    against conv_wgrad_split_kernel on the same tile and the same slab count: same MFMA order per accumulator and the
+    same slab reduce => the weight gradients are bit-identical (with and without the fused BN + ReLU on X)."""
+    from pytorch_kaldi_resnet_amd import tiling
+    B, Cin, Cout, H, Wd, stride = shape
+    old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS)
+    ops.SPLIT = 3
+    try:
+        torch.manual_seed(11)
+        x = torch.randn(B, H, Wd, Cin, device="cuda")
+        OH, OW = ops.conv_out_hw(H, Wd, 3, stride)
+        dy = torch.randn(B, OH, OW, Cout, device="cuda") * 1e-3
+        sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+        res = {}
+        for ws in (False, True):
+            ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS = ws, tiling.WGRAD_TARGET_BLOCKS
+            dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+            ops.conv_wgrad(x, dy, dw, 3, stride)
+            dw2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+            ops.conv_wgrad(x, dy, dw2, 3, stride, in_affine=(sc, sh), accumulate=True)
+            res[ws] = (dw, dw2)
+        assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double().cpu(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(),
+                                          stride=stride, padding=1)
+        err = (res[True][0].double().cpu() - ref).norm() / ref.norm()
+        assert err < 1e-5, err
+    finally:
+        ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS = old
+
+
 def test_bn_apply_sign_mask(ops):
     """spk_bn_apply's optional 1-bit output: bit k of word j of a pixel = (out[pixel][32 j + k] > 0)."""
     torch.manual_seed(1)
