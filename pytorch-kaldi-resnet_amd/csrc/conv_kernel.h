@@ -1,5 +1,6 @@
 #pragma once
 #include "spk_common.h"
+#include <type_traits>
 
 #ifndef STAGE_U
 #define STAGE_U 4   // staging loads in flight per thread
@@ -77,8 +78,19 @@ struct ConvArgs {
                       // per 32-channel chunk is too short to amortise a staging phase
 };
 
-template <int MT, int NT, bool BNBWD, int SPLIT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+// PIPE (f16x3, nine taps, one plane per chunk): the staging of chunk ch + 1 is woven into the K loop of chunk ch IN THE SAME
+// WAVE - after the matrix instructions of tap t the wave converts and writes staging item t of the next chunk into the other
+// half of a two-slot LDS tile (its global load was issued PIPE_D taps earlier), one barrier per chunk.  Why in the same wave:
+// on gfx950 the VALU instructions of one wave do not run under the MFMAs of ANOTHER wave of the SIMD (tools/probe/
+// issue_probe.hip: MFMA-only wave + VALU-only wave = the sum of their times, s_setprio or not), only independent VALU work
+// that follows an MFMA in the same instruction stream does; staging done as a separate phase - or by separate producer
+// waves - is therefore paid in full on top of the matrix time.
+#define PIPE_D 3
+#ifndef PIPE_VPM
+#define PIPE_VPM 4      // VALU instructions scheduled behind every MFMA of a pipelined tap
+#endif
+template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE>
+static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
     constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
     };
 
+    f32x4 pb0[PIPE ? 2 : 1][NT], pb1[PIPE ? 2 : 1][NT], pb2[PIPE ? 2 : 1][NT];     // PIPE: B fragments, carried from chunk to chunk
     for (int ch = 0; ch < nchunks; ++ch) {
         if constexpr (SPLIT == 0) {
             // K loop over (tap, 8-cin group), software-pipelined one group ahead: while the 4*MT*NT MFMAs of a group
@@ -407,6 +420,117 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #endif
                     }
             };
+            if constexpr (PIPE) {
+                static_assert(SPLIT == 3 && !BNBWD, "PIPE: f16x3 operands, plain input mode");
+                // a.ntaps == 9, a.kc == 1 (checked by the launcher); LDS holds two tiles of plane_floats
+                const int plane4 = halo_pix * LP4;                       // 16-byte units per tile
+                const f32x4* cur4 = lds4 + (ch & 1) * plane4;
+                float* nxt = lds + ((ch + 1) & 1) * plane_floats;
+                const bool more = ch + 1 < nchunks;
+                // Branch-free staging (a branch would end the scheduling region and with it the interleave): every item is
+                // loaded, transformed and written; items that do not exist (beyond the halo, or after the last chunk) read
+                // a safe address and write a dump pixel behind the two tiles.
+                const int cn = (more ? ch + 1 : ch) * CK + quad * 4;     // this thread's channels in the next chunk
+                const bool aff = (flags & SPK_IN_AFFINE_RELU) != 0;
+                f32x4 scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
+                if (aff) {
+                    scn = *(const f32x4*)(a.in_scale + cn);
+                    shn = *(const f32x4*)(a.in_shift + cn);
+                }
+                const float floor_v = aff ? 0.f : -__builtin_inff();     // ReLU only with the fused input transform
+                float* dump = lds + 2 * plane_floats;
+                f32x4 pre[PIPE_D];
+                unsigned inbm = 0;
+                auto issue = [&](auto uc) {                              // global load of staging item u of the next chunk
+                    constexpr int u = decltype(uc)::value;
+                    if constexpr (u >= 9) return;
+                    const int p = min(prow + PPP * u, halo_pix - 1);
+                    const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                    const int hx = p - hy * a.halo_w;
+                    const int iy = iy0 + hy, ix = ix0 + hx;
+                    const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                    inbm |= ok ? 1u << u : 0u;
+                    const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
+                    pre[u % PIPE_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+                };
+                auto finish = [&](auto uc) {                             // transform + fp16 split + LDS write of item u
+                    constexpr int u = decltype(uc)::value;
+                    const int p = prow + PPP * u;
+                    f32x4 w = pre[u % PIPE_D] * scn + shn;
+                    const bool ok = (inbm >> u) & 1u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
+                    const bool real = more && p < halo_pix;
+                    store_px(real ? nxt : dump, real ? p : 0, w);
+                };
+                f32x4 aq[NTERM][MT];
+                auto pstep = [&](const f32x4 (*bc)[NT], f32x4 (*bn)[NT], int o_next, int w_n2, int g_n2, auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    // One scheduling region per tap: MT*NT*3 matrix instructions, the A fragments of the next tap, the B
+                    // fragments two taps ahead, and one staging item of the next chunk (finish u, issue u + PIPE_D).  A
+                    // wave's VALU instruction only overlaps an MFMA that directly precedes it in its own stream, so the
+                    // item's ~60 VALU instructions are dealt out a few after every MFMA (sched_group_barrier pattern below)
+                    // instead of following the whole group.
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(bn, w_n2, g_n2);
+                    finish(uc);                                           // (reads pre[u % PIPE_D] before the next line refills it)
+                    issue(std::integral_constant<int, u + PIPE_D>{});
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int sum = Cfg::MAXSUM; sum >= 0; --sum)
+#pragma unroll
+                            for (int sa = 0; sa < NTERM; ++sa) {
+                                const int sb = sum - sa;
+                                if (sb < 0 || sb >= NTERM) continue;
+#pragma unroll
+                                for (int j = 0; j < NT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[sa][i]),
+                                                                                      __builtin_bit_cast(f16x8, bc[sb][j]), acc[i][j], 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int s = 0; s < NTERM; ++s) aq[s][i] = cur4[lbase[i] + o_next + s * (CK / 8)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < MT * NT * 3; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, PIPE_VPM, 0);     // a few VALU instructions in its shadow
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // (an LDS write of the item when one is ready)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if (ch == 0) {                   // first chunk: staged the plain way into slot 0
+                    __syncthreads();
+                    stage_chunk(0);
+                    __syncthreads();
+                }
+                if (ch == 0) {
+                    load_b(pb0, a.tap_w[0], a.tap_g[0]);
+                    load_b(pb1, a.tap_w[1], a.tap_g[1]);
+                }
+#pragma unroll
+                for (int s = 0; s < NTERM; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) aq[s][i] = cur4[lbase[i] + a.tap_off[0] + s * (CK / 8)];
+                issue(std::integral_constant<int, 0>{});
+                issue(std::integral_constant<int, 1>{});
+                issue(std::integral_constant<int, 2>{});
+#define IC(n) std::integral_constant<int, n>{}
+                // the last two taps fetch the B fragments of the NEXT chunk's taps 0 and 1 (group offset + one chunk) into the
+                // buffers that chunk starts from; after the last chunk they re-read its own (unused)
+                const int gn = more ? 1 : 0;           // one K group = one 16-channel plane (kc == 1)
+                pstep(pb0, pb2, a.tap_off[1], a.tap_w[2], a.tap_g[2], IC(0));
+                pstep(pb1, pb0, a.tap_off[2], a.tap_w[3], a.tap_g[3], IC(1));
+                pstep(pb2, pb1, a.tap_off[3], a.tap_w[4], a.tap_g[4], IC(2));
+                pstep(pb0, pb2, a.tap_off[4], a.tap_w[5], a.tap_g[5], IC(3));
+                pstep(pb1, pb0, a.tap_off[5], a.tap_w[6], a.tap_g[6], IC(4));
+                pstep(pb2, pb1, a.tap_off[6], a.tap_w[7], a.tap_g[7], IC(5));
+                pstep(pb0, pb2, a.tap_off[7], a.tap_w[8], a.tap_g[8], IC(6));
+                pstep(pb1, pb0, a.tap_off[8], a.tap_w[0], a.tap_g[0] + gn, IC(7));
+                pstep(pb2, pb1, a.tap_off[8], a.tap_w[1], a.tap_g[1] + gn, IC(8));
+#undef IC
+                __syncthreads();                 // slot (ch + 1) & 1 is complete, slot ch & 1 is free
+            } else
             {
                 // Three-deep operand pipeline.  A step (one tap of a 16-channel plane) is only 6*MT*NT MFMAs of 32 cycles -
                 // about half a microsecond, less than an L2 round trip - so the B fragments are requested TWO steps
@@ -600,3 +724,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 }
 
+template <int MT, int NT, bool BNBWD, int SPLIT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    conv_body<MT, NT, BNBWD, SPLIT, false>(a);
+}
+
+// the in-wave pipelined form (f16x3 operands; conv_pipe.hip)
+template <int MT, int NT, bool BNBWD>
+__global__ __launch_bounds__(256, 2) void conv_pipe_kernel(ConvArgs a) {        // two blocks per CU: 256 registers per lane
+    conv_body<MT, NT, BNBWD, 3, true>(a);
+}

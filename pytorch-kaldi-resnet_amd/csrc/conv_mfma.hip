@@ -22,6 +22,8 @@
 
 // bf16-split instantiations live in their own translation unit (conv_split.hip)
 int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, int split, hipStream_t st);
+// in-wave pipelined form (conv_pipe.hip)
+int spk_launch_conv_pipe(const ConvArgs& a, size_t lds_bytes, int MT, int NT, hipStream_t st);
 // wave-specialised persistent form (conv_ws.hip)
 int spk_launch_conv_ws(const ConvArgs& a, int MT, int NT, int WC, int split, int lp4, hipStream_t st);
 
@@ -141,6 +143,16 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
             a.tap_boff[t] = (int)off;
         }
         return spk_launch_conv_ws(a, MT, NT, ws_wc, split, lp4, st);
+    }
+    if (flags & SPK_CONV_PIPE) {
+        SPK_REQUIRE(split == 3 && kc == 1 && ntaps == 9 && !(flags & SPK_IN_BNBWD),
+                    "spk_conv_mfma: the pipelined kernel needs f16x3 operands, 9 taps, kc = 1 and a plain input");
+        SPK_REQUIRE(a.halo_h * a.halo_w <= 9 * 64, "spk_conv_mfma: the pipelined kernel stages at most 576 halo pixels (%d x %d)", a.halo_h, a.halo_w);
+        size_t lds2 = (2 * (size_t)a.halo_h * a.halo_w + 1) * lp4 * 16;      // two tiles + the dump pixel
+        if (lds2 < red_bytes) lds2 = red_bytes;
+        SPK_REQUIRE(lds2 <= 160 * 1024, "spk_conv_mfma: two halo tiles %dx%d need %zu B of LDS", a.halo_h, a.halo_w, lds2);
+        a.flags = flags & ~SPK_CONV_PIPE;
+        return spk_launch_conv_pipe(a, lds2, MT, NT, st);
     }
     if (split) return spk_launch_conv_split(a, lds_bytes, MT, NT, split, st);
 #define CASE(M, N) if (MT == M && NT == N) return launch_conv<M, N>(a, lds_bytes, st)

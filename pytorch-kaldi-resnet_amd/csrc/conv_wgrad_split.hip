@@ -28,6 +28,31 @@ static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Block -> (pixel-region slice g, channel-group pair m).  All Cin/32 x Cout/(32 WN) blocks of a slice walk the same regions
+// at the same time and re-read the same X and dY tiles, so they are given adjacent places in launch order ON ONE XCD
+// (hardware deals consecutive block ids to the eight XCDs in turn): the re-reads hit that XCD's L2 instead of going to
+// memory Cout/(32 WN) + Cin/32 times (the 1x1 convolutions of the Bottleneck blocks are bound by exactly that traffic).
+struct WgradBlock { int g, ci0, co0; };
+template <int WN>
+static __device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
+    const int ncgi = a.Cin >> 5, M = ncgi * (a.Cout / (32 * WN));
+    const int bid = blockIdx.x;
+    int g, m;
+    if ((a.nsplit & 7) == 0) {
+        const int k = bid >> 3;
+        m = k % M;
+        g = (k / M) * 8 + (bid & 7);
+    } else {
+        m = bid % M;
+        g = bid / M;
+    }
+    WgradBlock r;
+    r.g = g;
+    r.ci0 = (m % ncgi) * 32;
+    r.co0 = (m / ncgi) * (32 * WN);
+    return r;
+}
+
 // NTAPS = 9: 3x3 (pad 1); NTAPS = 1: 1x1 (pad 0; the f16x3 mode also runs the Bottleneck / downsample 1x1 convolutions here)
 template <int NTAPS, int WK, int WN, int SPLIT, int NX>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
@@ -39,8 +64,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int wk = wave / WN, wn = wave % WN;
-    const int ci0 = blockIdx.y * 32;
-    const int co0 = blockIdx.z * (32 * WN);
+    const WgradBlock wb = wgrad_block<WN>(a);
+    const int ci0 = wb.ci0, co0 = wb.co0;
     const int halo_pix = a.halo_h * a.halo_w;
     const int npix = a.TH * a.TW;
     const int nsteps_all = (npix + 15) >> 4;              // k-steps of 16 pixels; the padding rows of dY are zero
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
             }
     };
 
-    int region = blockIdx.x;
+    int region = wb.g;
     if (region < a.nregions) prefetch(region);
     for (; region < a.nregions; region += a.nsplit) {
         __syncthreads();   // previous region fully consumed
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
         }
     }
     if (wk == 0) {
-        float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
+        float* slab = a.partial + (size_t)wb.g * NTAPS * a.Cin * a.Cout;
         const float inv_x = 1.f / sig_x, inv_d = 1.f / sig_d;           // powers of two: exact; applied one after the other
                                                                          // (their product may leave the fp32 range)
 #pragma unroll
@@ -312,8 +337,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
     const int wave = wave8 & 3;
     const int h = lane >> 5;
     const int wk = wave / WN, wn = wave % WN;
-    const int ci0 = blockIdx.y * 32;
-    const int co0 = blockIdx.z * (32 * WN);
+    const WgradBlock wb = wgrad_block<WN>(a);
+    const int ci0 = wb.ci0, co0 = wb.co0;
     const int halo_pix = a.halo_h * a.halo_w;
     const int npix = a.TH * a.TW;
     const int nsteps_all = (npix + 15) >> 4;
@@ -322,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
     const int flags = a.flags;
     const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
     const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
-    const int nmine = (a.nregions - (int)blockIdx.x + a.nsplit - 1) / a.nsplit;     // regions of this block (>= 1)
+    const int nmine = (a.nregions - wb.g + a.nsplit - 1) / a.nsplit;     // regions of this block (>= 1)
 
     f32x16 acc[NTAPS];
     if (producer) {
@@ -414,9 +439,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
                 }
             }
         };
-        // region of this block's i-th turn: blockIdx.x + i * nsplit.  Barrier i: slot i & 1 is complete and the consumers
+        // region of this block's i-th turn: g + i * nsplit.  Barrier i: slot i & 1 is complete and the consumers
         // are done with slot (i + 1) & 1.
-        const int r0 = blockIdx.x, rs = a.nsplit;
+        const int r0 = wb.g, rs = a.nsplit;
         prefetch(pxA, pdA, inxA, indA, r0);
         if (nmine > 1) prefetch(pxB, pdB, inxB, indB, r0 + rs);
         for (int i = 0; i < nmine; i += 2) {
@@ -511,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
         }
     }
     if (!producer && wk == 0) {
-        float* slab = a.partial + (size_t)blockIdx.x * NTAPS * a.Cin * a.Cout;
+        float* slab = a.partial + (size_t)wb.g * NTAPS * a.Cin * a.Cout;
         const float inv_x = 1.f / sig_x, inv_d = 1.f / sig_d;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
@@ -532,7 +557,7 @@ static int launch_ws(const WgradArgs& a, hipStream_t st) {
     const size_t red_bytes = (WK > 1) ? (size_t)WN * NTAPS * 16 * 64 * sizeof(float) : 0;
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(ws): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
-    dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
+    dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / (32 * WN)));       // see wgrad_block
     if (a.halo_h * a.halo_w <= 32 * 4) hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, WK, WN, 4>), grid, dim3(512), lds_bytes, st, a);
     else hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, WK, WN, WGRAD_NX>), grid, dim3(512), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_wgrad(ws)");
@@ -554,7 +579,7 @@ static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
     const size_t red_bytes = (WK > 1) ? (size_t)WN * NTAPS * 16 * 64 * sizeof(float) : 0;
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(split): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
-    dim3 grid(a.nsplit, a.Cin / 32, a.Cout / (32 * WN));
+    dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / (32 * WN)));       // see wgrad_block
     const bool small = a.halo_h * a.halo_w <= 32 * 4;
     if (split == 3) {
         if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, 4>), grid, dim3(256), lds_bytes, st, a);

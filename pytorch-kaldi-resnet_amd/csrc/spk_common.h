@@ -33,7 +33,9 @@ enum {
     SPK_EPI_STATS = 16,       // per-wave per-channel (sum, sumsq) of the stored values
     SPK_EPI_BNBWD = 32,       // with EPI_STATS: (sum dz, sum dz*xhat) of the BatchNorm the output is a gradient of
     SPK_IN_BNBWD = 64,        // the staged input is BatchNorm-backward(in) computed on the fly (stride-1 data gradients)
-    SPK_CONV_WS = 128         // launch the producer/consumer (wave-specialised, persistent) kernel: bf16-split 3x3 only
+    SPK_CONV_WS = 128,        // launch the producer/consumer (wave-specialised, persistent) kernel: bf16-split 3x3 only
+                              //   (bits 8-9 of the flags word then carry log2 of its consumer-wave channel groups)
+    SPK_CONV_PIPE = 1024      // launch the in-wave pipelined kernel (conv_kernel.h, PIPE): f16x3, 3x3, plain input
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPK_LIB", os.path.join(_HERE, "libspkhip.so"))   # SPK_LIB: A/B builds of the same ABI
 
 IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD, IN_BNBWD, CONV_WS = 1, 2, 4, 8, 16, 32, 64, 128
+CONV_PIPE = 1024
 MASK_NONE, MASK_ACT, MASK_RAW = 0, 1, 2
 
 _P = ctypes.c_void_p

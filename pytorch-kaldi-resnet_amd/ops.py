@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import hip, tiling
-from .hip import (CONV_WS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
+from .hip import (CONV_PIPE, CONV_WS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
                   MASK_RAW,
                   call, ptr, stream)
 
@@ -120,6 +120,10 @@ SPLIT_BWD = MFMA_MODES[os.environ["SPK_MFMA_BWD"]] if os.environ.get("SPK_MFMA_B
 WS_CONV = os.environ.get("SPK_CONV_WS", "auto")
 assert WS_CONV in ("0", "1", "auto"), "SPK_CONV_WS must be 0, 1 or auto"
 WS_AUTO_MIN_COUT = 128
+# in-wave pipelined staging (conv_pipe_kernel): on by default for the f16x3 3x3 launches it covers; SPK_CONV_PIPE=0 disables
+PIPE_CONV = os.environ.get("SPK_CONV_PIPE", "1") == "1"
+PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
+PIPE_MAX_LDS = int(os.environ.get("SPK_PIPE_MAX_LDS", str(80 * 1024)))      # two halo tiles; <= 80 KiB keeps two blocks per CU
 # the same idea for the 3x3 weight gradients (f16x3 mode): eight-wave blocks, one per CU (conv_wgrad_ws_kernel).  Opt-in:
 # bit-identical, but 10-15 % SLOWER than conv_wgrad_split_kernel on every layer (tools/wg_abl3.sh, profiles/r02_wgrad_ablation.log:
 # producers alone 0.31 ms, consumers alone 0.28 ms, together 0.49 ms - the staging is VALU-bound and a SIMD does not run one
@@ -230,6 +234,12 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
                 kc = cand
                 break
     flags = 0
+    # in-wave pipelined kernel (csrc/conv_kernel.h, PIPE): f16x3 3x3 launches with a plain input whose two halo tiles fit
+    halo9 = ((TH - 1) * IS + key[3]) * ((TW - 1) * IS + key[4])
+    pipe = (PIPE_CONV and ws is None and split == 3 and len(taps) == 9 and kc == 1 and in_bnbwd is None and halo9 <= 576
+            and (2 * halo9 + 1) * 80 <= PIPE_MAX_LDS and Cin >= PIPE_MIN_CIN)
+    if pipe:
+        flags |= CONV_PIPE
     if ws is not None:
         flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
     if in_affine is not None:
@@ -273,6 +283,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
          stream(),
          label=(("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
+                else "conv_pipe_kernel<%d,%d,false>" % (MT, NT) if pipe
                 else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split)) + (
              " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps),

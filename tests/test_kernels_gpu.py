@@ -271,6 +271,42 @@ def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
         ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS = old
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 19, 45, 1), (2, 64, 64, 23, 41, 1), (3, 64, 128, 20, 27, 2), (2, 128, 128, 20, 75, 1),
+                                   (2, 256, 256, 10, 38, 1), (1, 128, 64, 9, 13, 2)])
+def test_pipelined_conv_equals_the_reference_kernel(ops, shape):
+    """conv_pipe_kernel (next chunk staged inside the current chunk's K loop, two LDS tiles, csrc/conv_kernel.h PIPE)
+    against conv_mfma_kernel on the same tiles: same MFMA order per accumulator => bit-identical outputs and statistics,
+    for the forward (fused input BN + ReLU, epilogue affine / add / ReLU) and the plain data gradient (stride 1 and 2)."""
+    B, Cin, Cout, H, Wd, stride = shape
+    old = (ops.SPLIT, ops.PIPE_CONV)
+    ops.SPLIT = 3
+    try:
+        torch.manual_seed(3)
+        x = torch.randn(B, H, Wd, Cin, device="cuda")
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+        wpk, wpk_t = ops.pack_conv_weight(w), ops.pack_conv_weight(w, True)
+        sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+        e2 = torch.rand(2, Cout, device="cuda") + 0.5
+        OH, OW = ops.conv_out_hw(H, Wd, 3, stride)
+        dy = torch.randn(B, OH, OW, Cout, device="cuda")
+        res_in = torch.randn(B, OH, OW, Cout, device="cuda")
+        dadd = torch.randn(B, H, Wd, Cin, device="cuda")
+        res = {}
+        for pipe in (False, True):
+            ops.PIPE_CONV = pipe
+            out, st = ops.conv_fwd(x, wpk, Cout, 3, stride, in_affine=(sc, sh), stats=True)
+            out2, _ = ops.conv_fwd(x, wpk, Cout, 3, stride, epi_affine=(e2[0], e2[1]), epi_add=res_in, relu=True)
+            dx = ops.conv_dgrad(dy, wpk_t, Cin, 3, stride, (H, Wd), add=dadd)
+            res[pipe] = (out, st, out2, dx)
+        for a, b in zip(res[False], res[True]):
+            assert torch.equal(a, b)
+        ref = torch.nn.functional.conv2d(torch.relu(x * sc + sh).permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), stride=stride, padding=1)
+        err = (res[True][0].permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()
+        assert err < 1e-5, err
+    finally:
+        ops.SPLIT, ops.PIPE_CONV = old
+
+
 def test_bn_apply_sign_mask(ops):
     """spk_bn_apply's optional 1-bit output: bit k of word j of a pixel = (out[pixel][32 j + k] > 0)."""
     torch.manual_seed(1)
