@@ -15,7 +15,8 @@
 
 // bf16-split instantiations live in conv_wgrad_split.hip
 int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st);
-int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);        // conv_wgrad_split.hip: producer / consumer form
+int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);
+int spk_launch_wgrad_pipe(const WgradArgs& a, int WN, hipStream_t st);      // conv_wgrad_pipe.hip: in-wave pipelined form        // conv_wgrad_split.hip: producer / consumer form
 
 template <int NTAPS, int WK, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -283,6 +284,8 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
                 "spk_conv_wgrad: tensor too large");
     SPK_REQUIRE((long long)IH * IW * Cin * 4 < 4294967295LL && (long long)OH * OW * Cout * 4 < 4294967295LL,
                 "spk_conv_wgrad: one image exceeds 32-bit byte offsets");
+    SPK_REQUIRE((long long)IW * Cin * 4 < (1 << 24) && (long long)OW * Cout * 4 < (1 << 24) && IH < (1 << 24) && OH < (1 << 24),
+                "spk_conv_wgrad: a tensor row exceeds the 24-bit multiplier range");
     WgradArgs a;
     a.x = x; a.dy = dy; a.partial = partial; a.in_scale = in_scale; a.in_shift = in_shift;
     a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
@@ -302,6 +305,11 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
                 a.halo_h, a.halo_w, 32 * WGRAD_NX);
     SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
                 TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
+    if (flags & SPK_CONV_PIPE) {
+        SPK_REQUIRE(split == 3 && ksize == 3, "spk_conv_wgrad: the pipelined kernel exists for 3x3 in the f16x3 mode");
+        a.flags = flags & ~SPK_CONV_PIPE;
+        return spk_launch_wgrad_pipe(a, WN, (hipStream_t)stream);
+    }
     if (flags & SPK_CONV_WS) {
         SPK_REQUIRE(split == 3 && ksize == 3, "spk_conv_wgrad: the producer / consumer kernel exists for 3x3 in the f16x3 mode");
         a.flags = flags & ~SPK_CONV_WS;

@@ -109,3 +109,9 @@ static __device__ __forceinline__ void spk_wave_amax_commit(float v, unsigned* d
 }
 #endif
 
+// Small-range integer arithmetic on the full-rate 24-bit multiplier (v_mul_u32_u24; the 32-bit v_mul_lo / v_mul_hi run at a
+// quarter of the VALU rate and the staging code of the conv kernels is VALU-bound): p / d for p < 2048 and p * d < 2^20 with
+// m20 = ceil(2^20 / d), derived from the 32-bit reciprocal the launchers already pass (ceil(2^32 / d)).
+static __device__ __forceinline__ unsigned spk_m20(unsigned magic32) { return (magic32 + 0xFFFu) >> 12; }
+static __device__ __forceinline__ int spk_div20(int p, unsigned m20) { return (int)(__umul24((unsigned)p, m20) >> 20); }
+

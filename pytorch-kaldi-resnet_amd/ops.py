@@ -122,6 +122,11 @@ assert WS_CONV in ("0", "1", "auto"), "SPK_CONV_WS must be 0, 1 or auto"
 WS_AUTO_MIN_COUT = 128
 # in-wave pipelined staging (conv_pipe_kernel): on by default for the f16x3 3x3 launches it covers; SPK_CONV_PIPE=0 disables
 PIPE_CONV = os.environ.get("SPK_CONV_PIPE", "1") == "1"
+# the same for the 3x3 weight gradients (conv_wgrad_pipe_kernel): opt-in.  Bit-identical, but no faster than
+# conv_wgrad_split_kernel (+2..6 % on the 32/64-channel layers, -1..-12 % elsewhere, profiles/r02_wgrad_ablation.log): a tap of
+# the weight gradient has three matrix instructions against ~60 VALU instructions of a staging item, so the VALU stream sets the
+# pace with or without the overlap
+PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
 PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
 PIPE_MAX_LDS = int(os.environ.get("SPK_PIPE_MAX_LDS", str(80 * 1024)))      # two halo tiles; <= 80 KiB keeps two blocks per CU
 # the same idea for the 3x3 weight gradients (f16x3 mode): eight-wave blocks, one per CU (conv_wgrad_ws_kernel).  Opt-in:
@@ -477,15 +482,20 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
     wgws = (WS_WGRAD and split == 3 and ksize == 3
             and 2 * (halo * 192 + -(-(TH * TW) // 16) * 16 * (WN * 192 + (64 if WN > 1 else 0))) <= 160 * 1024)
+    # in-wave pipelined kernel (csrc/conv_wgrad_pipe.hip): two planar LDS slots of 64-byte rows
+    nst = -(-(TH * TW) // 16)                                   # k-steps of the tile: one or two per wave group
+    wgp = (PIPE_WGRAD and not wgws and split == 3 and ksize == 3 and nst % (4 // WN) == 0 and nst // (4 // WN) in (1, 2)
+           and 2 * (2 * halo * 64 + 2 * WN * -(-(TH * TW) // 16) * 16 * 64) + 128 <= PIPE_MAX_LDS)
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else None))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
     ws = _workspace(nbytes, x.device)
-    flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0)
+    flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0) | (CONV_PIPE if wgp else 0)
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
          label=("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
+         else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp
          else ("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
              ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),

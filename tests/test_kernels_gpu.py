@@ -241,12 +241,13 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape, w
 @pytest.mark.parametrize("shape", [(3, 32, 32, 16, 40, 1), (2, 64, 128, 21, 37, 1), (2, 128, 128, 20, 75, 1), (4, 64, 128, 20, 31, 2),
                                    (2, 256, 256, 10, 38, 1)])
 def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
-    """conv_wgrad_ws_kernel (eight waves: four stage the next region, four run the MFMAs; csrc/conv_wgrad_split.hip)
+    """conv_wgrad_ws_kernel (eight waves: four stage the next region, four run the MFMAs; csrc/conv_wgrad_split.hip) and
+    conv_wgrad_pipe_kernel (the next region staged inside the K loop of the current one, csrc/conv_wgrad_pipe.hip)
     against conv_wgrad_split_kernel on the same tile and the same slab count: same MFMA order per accumulator and the
     same slab reduce => the weight gradients are bit-identical (with and without the fused BN + ReLU on X)."""
     from pytorch_kaldi_resnet_amd import tiling
     B, Cin, Cout, H, Wd, stride = shape
-    old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS)
+    old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD)
     ops.SPLIT = 3
     try:
         torch.manual_seed(11)
@@ -255,20 +256,21 @@ def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
         dy = torch.randn(B, OH, OW, Cout, device="cuda") * 1e-3
         sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
         res = {}
-        for ws in (False, True):
-            ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS = ws, tiling.WGRAD_TARGET_BLOCKS
+        for ws in (False, True, "pipe"):
+            ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD = ws is True, tiling.WGRAD_TARGET_BLOCKS, ws == "pipe"
             dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
             ops.conv_wgrad(x, dy, dw, 3, stride)
             dw2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
             ops.conv_wgrad(x, dy, dw2, 3, stride, in_affine=(sc, sh), accumulate=True)
             res[ws] = (dw, dw2)
         assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+        assert torch.equal(res[False][0], res["pipe"][0]) and torch.equal(res[False][1], res["pipe"][1])      # conv_wgrad_pipe_kernel
         ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double().cpu(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double().cpu(),
                                           stride=stride, padding=1)
         err = (res[True][0].double().cpu() - ref).norm() / ref.norm()
         assert err < 1e-5, err
     finally:
-        ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS = old
+        ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD = old
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 19, 45, 1), (2, 64, 64, 23, 41, 1), (3, 64, 128, 20, 27, 2), (2, 128, 128, 20, 75, 1),
