@@ -87,9 +87,9 @@ struct ConvArgs {
 // waves - is therefore paid in full on top of the matrix time.
 #define PIPE_D 3
 #ifndef PIPE_VPM
-#define PIPE_VPM 4      // VALU instructions scheduled behind every MFMA of a pipelined tap
+#define PIPE_VPM 6      // VALU instructions scheduled behind every MFMA of a pipelined tap (2 / 4 / 6 / 8 measured: 57.08 / 57.29 / 56.94 / 56.9 ms per step)
 #endif
-template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE>
+template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false>
 static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
     constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
@@ -421,7 +421,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     }
             };
             if constexpr (PIPE) {
-                static_assert(SPLIT == 3 && !BNBWD, "PIPE: f16x3 operands, plain input mode");
+                static_assert(SPLIT == 3, "PIPE: f16x3 operands");
                 // a.ntaps == 9, a.kc == 1 (checked by the launcher); LDS holds two tiles of plane_floats
                 const int plane4 = halo_pix * LP4;                       // 16-byte units per tile
                 const f32x4* cur4 = lds4 + (ch & 1) * plane4;
@@ -431,37 +431,102 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                 // loaded, transformed and written; items that do not exist (beyond the halo, or after the last chunk) read
                 // a safe address and write a dump pixel behind the two tiles.
                 const int cn = (more ? ch + 1 : ch) * CK + quad * 4;     // this thread's channels in the next chunk
+                float* dump = lds + 2 * plane_floats;
+                unsigned inbm = 0;
+                // ---- plain input (optionally BN + ReLU of the producing layer) ----
                 const bool aff = (flags & SPK_IN_AFFINE_RELU) != 0;
                 f32x4 scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
-                if (aff) {
+                if (!BNBWD && aff) {
                     scn = *(const f32x4*)(a.in_scale + cn);
                     shn = *(const f32x4*)(a.in_shift + cn);
                 }
                 const float floor_v = aff ? 0.f : -__builtin_inff();     // ReLU only with the fused input transform
-                float* dump = lds + 2 * plane_floats;
                 f32x4 pre[PIPE_D];
-                unsigned inbm = 0;
-                auto issue = [&](auto uc) {                              // global load of staging item u of the next chunk
+                // ---- fused BatchNorm backward (see stage_chunk): value = k1*(dz - m1 - xhat*m2), dz = in*mask ----
+                f32x4 prr[BNBWD ? PIPE_D : 1];                           // raw conv output of that BatchNorm
+                unsigned prm[BNBWD && BITS ? PIPE_D : 1], pof[BNBWD ? PIPE_D : 1];   // mask word, element offset in the image
+                unsigned corem = 0;                                      // bit u: item u is one of the tile's own pixels
+                f32x4 bmu = {}, bis = {}, bk1 = {}, bm1 = {}, bm2 = {}, bbsc = {}, bbsh = {};
+                if constexpr (BNBWD) {
+                    bmu = *(const f32x4*)(a.in_bn4 + cn);
+                    bis = *(const f32x4*)(a.in_bn4 + a.Cin + cn);
+                    if constexpr (!BITS) {
+                        bbsc = *(const f32x4*)(a.in_bn4 + 2 * a.Cin + cn);
+                        bbsh = *(const f32x4*)(a.in_bn4 + 3 * a.Cin + cn);
+                    }
+                    bk1 = *(const f32x4*)(a.in_coef + cn);
+                    bm1 = *(const f32x4*)(a.in_coef + a.Cin + cn);
+                    bm2 = *(const f32x4*)(a.in_coef + 2 * a.Cin + cn);
+                }
+                const bool owner = (cg == 0);
+                // side outputs of an item wait for the end of its tap (their stores are conditional: a branch)
+                f32x4 sd_w = {}, sd_dz = {};
+                unsigned sd_off = 0;
+                bool sd_go = false;
+                auto issue = [&](auto uc) {                              // global load(s) of staging item u of the next chunk
                     constexpr int u = decltype(uc)::value;
                     if constexpr (u >= 9) return;
                     const int p = min(prow + PPP * u, halo_pix - 1);
                     const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
                     const int hx = p - hy * a.halo_w;
                     const int iy = iy0 + hy, ix = ix0 + hx;
-                    const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-                    inbm |= ok ? 1u << u : 0u;
-                    const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
-                    pre[u % PIPE_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+                    const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
+                    inbm = (inbm & ~(1u << u)) | ((unsigned)ok << u);
+                    if constexpr (BNBWD) {
+                        const bool core = ok & (iy >= oy0) & (iy < oy0 + a.TH) & (ix >= ox0) & (ix < ox0 + a.TW);
+                        corem = (corem & ~(1u << u)) | ((unsigned)core << u);
+                        const unsigned pi = ok ? (unsigned)(iy * a.IW + ix) : pi_safe;
+                        const unsigned off = pi * (unsigned)a.Cin + (unsigned)cn;
+                        pof[u % PIPE_D] = off;
+                        pre[u % PIPE_D] = *(const f32x4*)(img_in + off);
+                        prr[u % PIPE_D] = *(const f32x4*)(img_raw + off);
+                        if constexpr (BITS) prm[u % PIPE_D] = img_mask[pi * (unsigned)(a.Cin >> 5) + (unsigned)(cn >> 5)];
+                    } else {
+                        const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
+                        pre[u % PIPE_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+                    }
                 };
                 auto finish = [&](auto uc) {                             // transform + fp16 split + LDS write of item u
                     constexpr int u = decltype(uc)::value;
                     const int p = prow + PPP * u;
-                    f32x4 w = pre[u % PIPE_D] * scn + shn;
                     const bool ok = (inbm >> u) & 1u;
+                    const bool real = more & (p < halo_pix);
+                    f32x4 w;
+                    if constexpr (BNBWD) {
+                        const f32x4 v = pre[u % PIPE_D], rw = prr[u % PIPE_D];
+                        f32x4 dz;
+                        if constexpr (BITS) {
+                            const unsigned bits = prm[u % PIPE_D] >> (cn & 31);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
-                    const bool real = more && p < halo_pix;
+                            for (int k = 0; k < 4; ++k) dz[k] = ((bits >> k) & 1u) ? v[k] : 0.f;
+                        } else {
+                            const f32x4 m = rw * bbsc + bbsh;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[k] : 0.f;
+                        }
+                        w = bk1 * (dz - bm1 - ((rw - bmu) * bis) * bm2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w[k] = ok ? w[k] : 0.f;
+                        sd_go = real & owner & (((corem >> u) & 1u) != 0);
+                        sd_w = w;
+                        sd_dz = dz;
+                        sd_off = pof[u % PIPE_D];
+                        const float mx = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
+                        side_mx = sd_go ? fmaxf(side_mx, mx) : side_mx;
+                    } else {
+                        w = pre[u % PIPE_D] * scn + shn;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
+                    }
                     store_px(real ? nxt : dump, real ? p : 0, w);
+                };
+                auto flush = [&]() {                                     // after the tap: the item's side outputs (tile's own pixels)
+                    if constexpr (BNBWD) {
+                        if (sd_go) {
+                            *(f32x4*)(img_draw + sd_off) = sd_w;
+                            if (img_dz) *(f32x4*)(img_dz + sd_off) = sd_dz;
+                        }
+                    }
                 };
                 f32x4 aq[NTERM][MT];
                 auto pstep = [&](const f32x4 (*bc)[NT], f32x4 (*bn)[NT], int o_next, int w_n2, int g_n2, auto uc) {
@@ -498,6 +563,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // (an LDS write of the item when one is ready)
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    flush();
                 };
                 if (ch == 0) {                   // first chunk: staged the plain way into slot 0
                     __syncthreads();
@@ -730,7 +796,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 }
 
 // the in-wave pipelined form (f16x3 operands; conv_pipe.hip)
-template <int MT, int NT, bool BNBWD>
+// BITS (fused BatchNorm backward only): the ReLU mask comes as sign bits (in_mask); otherwise it is recomputed from the raw
+// conv output (in_act is not supported here: such launches stay on conv_mfma_kernel)
+template <int MT, int NT, bool BNBWD, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(ConvArgs a) {        // two blocks per CU: 256 registers per lane
-    conv_body<MT, NT, BNBWD, 3, true>(a);
+    conv_body<MT, NT, BNBWD, 3, true, BITS>(a);
 }

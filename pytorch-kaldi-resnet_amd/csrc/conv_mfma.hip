@@ -145,8 +145,9 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
         return spk_launch_conv_ws(a, MT, NT, ws_wc, split, lp4, st);
     }
     if (flags & SPK_CONV_PIPE) {
-        SPK_REQUIRE(split == 3 && kc == 1 && ntaps == 9 && !(flags & SPK_IN_BNBWD),
-                    "spk_conv_mfma: the pipelined kernel needs f16x3 operands, 9 taps, kc = 1 and a plain input");
+        SPK_REQUIRE(split == 3 && kc == 1 && ntaps == 9, "spk_conv_mfma: the pipelined kernel needs f16x3 operands, 9 taps and kc = 1");
+        SPK_REQUIRE(!(flags & SPK_IN_BNBWD) || !in_act || in_mask,
+                    "spk_conv_mfma: the pipelined kernel takes the ReLU mask of a fused BatchNorm backward as sign bits or recomputes it");
         SPK_REQUIRE(a.halo_h * a.halo_w <= 9 * 64, "spk_conv_mfma: the pipelined kernel stages at most 576 halo pixels (%d x %d)", a.halo_h, a.halo_w);
         size_t lds2 = (2 * (size_t)a.halo_h * a.halo_w + 1) * lp4 * 16;      // two tiles + the dump pixel
         if (lds2 < red_bytes) lds2 = red_bytes;

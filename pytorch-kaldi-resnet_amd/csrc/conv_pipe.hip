@@ -4,14 +4,25 @@
 
 template <int MT, int NT>
 static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    if (a.flags & SPK_IN_BNBWD) {
+        // fused BatchNorm backward: the sign-bit form only (the form that recomputes the mask from the raw tensor has more
+        // VALU work per item than a tap has MFMA shadow and measured slower than conv_mfma_kernel), register tiles <= 2 x 2
+        if constexpr (MT * NT <= 4) {
+            SPK_REQUIRE(a.in_mask, "spk_conv_mfma: the pipelined fused-BatchNorm-backward kernel takes the ReLU mask as sign bits");
+            hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, true, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+        } else {
+            spk_set_error("spk_conv_mfma: no pipelined fused-BatchNorm-backward kernel for MT=%d NT=%d", MT, NT);
+            return -1;
+        }
+    } else
+        hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_mfma(pipe)");
     return 0;
 }
 
 int spk_launch_conv_pipe(const ConvArgs& a, size_t lds_bytes, int MT, int NT, hipStream_t st) {
 #define CASE(M, N) if (MT == M && NT == N) return launch_pipe<M, N>(a, lds_bytes, st);
-    CASE(1, 1) CASE(2, 1) CASE(3, 1) CASE(4, 1) CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(1, 4)
+    CASE(2, 1) CASE(3, 1) CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(1, 4)
 #undef CASE
     spk_set_error("spk_conv_mfma: unsupported pipelined tile config MT=%d NT=%d", MT, NT);
     return -1;

@@ -127,6 +127,10 @@ PIPE_CONV = os.environ.get("SPK_CONV_PIPE", "1") == "1"
 # the weight gradient has three matrix instructions against ~60 VALU instructions of a staging item, so the VALU stream sets the
 # pace with or without the overlap
 PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
+# ... and for the data gradients with the fused BatchNorm backward (sign-bit masks, register tiles <= 2 x 2): opt-in.  A fused
+# item is ~90 VALU instructions (~450 cycles) against the 384 MFMA cycles of a 2 x 2 tap, so the staging is not hidden: per launch
+# 0.75 vs 0.81 ms (64 channels) and 0.50 vs 0.54 ms (128 channels, against the wave-specialised kernel), nothing measurable per step
+PIPE_BNBWD = os.environ.get("SPK_PIPE_BNBWD", "0") == "1"
 PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
 PIPE_MAX_LDS = int(os.environ.get("SPK_PIPE_MAX_LDS", str(80 * 1024)))      # two halo tiles; <= 80 KiB keeps two blocks per CU
 # the same idea for the 3x3 weight gradients (f16x3 mode): eight-wave blocks, one per CU (conv_wgrad_ws_kernel).  Opt-in:
@@ -224,8 +228,11 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
     # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
     ws, WC = None, 1
+    # fused BatchNorm backward with the mask as sign bits on <= 128 output channels: optionally the in-wave pipelined kernel
+    pipe_fused = (PIPE_CONV and PIPE_BNBWD and split == 3 and in_bnbwd is not None and len(in_bnbwd) > 4 and MT * NT <= 4
+                  and Cout <= 128 and WS_FORCE is None and WS_CONV != "1")
     ws_on = WS_CONV == "1" or WS_FORCE is not None or (
-        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT)
+        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT and not pipe_fused)
     if split and ws_on and len(taps) >= WS_MIN_TAPS and ips == 1:
         ws = WS_FORCE or tiling.ws_tile(*key)
     if ws is not None:
@@ -241,7 +248,9 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     flags = 0
     # in-wave pipelined kernel (csrc/conv_kernel.h, PIPE): f16x3 3x3 launches with a plain input whose two halo tiles fit
     halo9 = ((TH - 1) * IS + key[3]) * ((TW - 1) * IS + key[4])
-    pipe = (PIPE_CONV and ws is None and split == 3 and len(taps) == 9 and kc == 1 and in_bnbwd is None and halo9 <= 576
+    # (fused BatchNorm backward: the ReLU mask as sign bits, or recomputed from the raw tensor - not read from an activation)
+    bnbwd_ok = in_bnbwd is None or pipe_fused
+    pipe = (PIPE_CONV and ws is None and split == 3 and len(taps) == 9 and kc == 1 and bnbwd_ok and halo9 <= 576
             and (2 * halo9 + 1) * 80 <= PIPE_MAX_LDS and Cin >= PIPE_MIN_CIN)
     if pipe:
         flags |= CONV_PIPE
@@ -288,7 +297,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
          stream(),
          label=(("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
-                else "conv_pipe_kernel<%d,%d,false>" % (MT, NT) if pipe
+                else ("conv_pipe_kernel<%d,%d,false,false>" % (MT, NT) if in_bnbwd is None else "conv_pipe_kernel<%d,%d,true,true>" % (MT, NT)) if pipe
                 else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split)) + (
              " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps),
