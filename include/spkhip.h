@@ -40,6 +40,13 @@ const char* spk_last_error(void);
                                 output gradient this launch produces (dz = out * mask; mask = bn_act > 0, or
                                 bn_raw*scale+shift > 0 when bn_act is NULL; bn4 = [mean, invstd, scale, shift][Cout]) */
 
+/* kernel form (results are bit-identical to the plain kernel on the same tile) */
+#define SPK_CONV_WS 128      /* producer / consumer form of spk_conv_mfma (split != 0, 9 taps, kc = 1; flags bits 8-9 = log2 of
+                                its consumer-wave channel groups) and of spk_conv_wgrad (split = 3, 3x3) */
+#define SPK_CONV_PIPE 1024   /* in-wave pipelined form: spk_conv_mfma (split = 3, 9 taps, kc = 1, <= 576 halo pixels, two halo
+                                tiles in LDS; with SPK_IN_BNBWD: in_mask given, MT*NT <= 4) and spk_conv_wgrad (split = 3, 3x3,
+                                tile of 1 or 2 k-steps of 16 pixels per wave group) */
+
 /* ---- convolutions --------------------------------------------------------------------------------- */
 
 /* nn.Conv2d weight [Cout][Cin][KH][KW] (scripts/model.py:12-15,105-110,233-234) -> MFMA fragment order
@@ -77,7 +84,8 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * the tensor's absmax or an upper estimate of it: gradients), three cross products on v_mfma_f32_32x32x16_f16, fp32
  * accumulation, accumulators scaled back by 1/(sigma_in * sigma_w).  Measured accuracy = the fp32 instruction's
  * (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the launch atomically maxes the float
- * bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume those tensors. */
+ * bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume those tensors.
+ * flags: the SPK_* bits above. */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
                   const float* in_act, const float* in_bn4, const float* in_coef, const unsigned* in_mask /* sign bits of
