@@ -9,6 +9,8 @@
 #define WGRAD_ND 4   // and for the dY tile: npix <= (256/(8*WN))*ND
 #endif
 
+#define WGRAD_MAX_PIX_1X1 64   // pixels per region of conv_wgrad_1x1_kernel (its prefetch registers are sized for this)
+
 struct WgradArgs {
     const float* x;
     const float* dy;

@@ -35,7 +35,8 @@ enum {
     SPK_IN_BNBWD = 64,        // the staged input is BatchNorm-backward(in) computed on the fly (stride-1 data gradients)
     SPK_CONV_WS = 128,        // launch the producer/consumer (wave-specialised, persistent) kernel: bf16-split 3x3 only
                               //   (bits 8-9 of the flags word then carry log2 of its consumer-wave channel groups)
-    SPK_CONV_PIPE = 1024      // launch the in-wave pipelined kernel (conv_kernel.h, PIPE): f16x3, 3x3, plain input
+    SPK_CONV_PIPE = 1024,     // launch the in-wave pipelined kernel (conv_kernel.h, PIPE): f16x3, 3x3, plain input
+    SPK_WGRAD_GROUPS = 2048   // spk_conv_wgrad, 1x1, f16x3: conv_wgrad_1x1_kernel with 1 << (flags bits 12-13) channel groups
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }

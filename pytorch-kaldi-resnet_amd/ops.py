@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import hip, tiling
-from .hip import (CONV_PIPE, CONV_WS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
+from .hip import (CONV_PIPE, CONV_WS, WGRAD_GROUPS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
                   MASK_RAW,
                   call, ptr, stream)
 
@@ -131,6 +131,8 @@ PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
 # item is ~90 VALU instructions (~450 cycles) against the 384 MFMA cycles of a 2 x 2 tap, so the staging is not hidden: per launch
 # 0.75 vs 0.81 ms (64 channels) and 0.50 vs 0.54 ms (128 channels, against the wave-specialised kernel), nothing measurable per step
 PIPE_BNBWD = os.environ.get("SPK_PIPE_BNBWD", "0") == "1"
+GROUPED_1X1 = os.environ.get("SPK_WGRAD_1X1_GROUPS", "1") == "1"   # 1x1 weight gradients: input-channel groups as "taps"
+GROUPED_1X1_BLOCKS = int(os.environ.get("SPK_WGRAD_1X1_BLOCKS", "512"))
 PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
 PIPE_MAX_LDS = int(os.environ.get("SPK_PIPE_MAX_LDS", str(80 * 1024)))      # two halo tiles; <= 80 KiB keeps two blocks per CU
 # the same idea for the 3x3 weight gradients (f16x3 mode): eight-wave blocks, one per CU (conv_wgrad_ws_kernel).  Opt-in:
@@ -495,15 +497,25 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     nst = -(-(TH * TW) // 16)                                   # k-steps of the tile: one or two per wave group
     wgp = (PIPE_WGRAD and not wgws and split == 3 and ksize == 3 and nst % (4 // WN) == 0 and nst // (4 // WN) in (1, 2)
            and 2 * (2 * halo * 64 + 2 * WN * -(-(TH * TW) // 16) * 16 * 64) + 128 <= PIPE_MAX_LDS)
-    nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else None))
+    # 1x1, f16x3: conv_wgrad_1x1_kernel with 2 or 4 input-channel groups per block (csrc/conv_wgrad_1x1.hip)
+    cg = 0
+    if GROUPED_1X1 and split == 3 and ksize == 1 and WN in (2, 4) and TH * TW <= 64:
+        cg = 4 if Cin % 128 == 0 else (2 if Cin % 64 == 0 else 0)
+        if cg and -(-(TH * TW) // 16) * 16 * (cg * 192 + WN * 192 + 64) > 80 * 1024:
+            cg = 2 if cg == 4 else 0
+    nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else (GROUPED_1X1_BLOCKS if cg else None),
+                                           cin_groups=cg or 1))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
     ws = _workspace(nbytes, x.device)
     flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0) | (CONV_PIPE if wgp else 0)
+    if cg:
+        flags |= WGRAD_GROUPS | ({2: 1, 4: 2}[cg] << 12)
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
+         label=("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
+         else ("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
          else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp
          else ("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
              ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split

@@ -242,8 +242,8 @@ def _wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=0):
 WGRAD_TARGET_BLOCKS = int(_os.environ.get('SPK_WGRAD_BLOCKS', '512'))      # persistent wgrad blocks per launch = 2 per CU x 256 CUs (measured best of 512/768/1024)
 
 
-def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=None):
-    per = (Cin // 32) * (Cout // (32 * WN))
+def wgrad_nsplit(nregions, Cin, Cout, WN, target_blocks=None, cin_groups=1):
+    per = (Cin // (32 * cin_groups)) * (Cout // (32 * WN))
     return max(1, min(nregions, (target_blocks or WGRAD_TARGET_BLOCKS) // per))
 
 
