@@ -47,6 +47,9 @@ const char* spk_last_error(void);
                                 tiles in LDS; with SPK_IN_BNBWD: in_mask given, MT*NT <= 4) and spk_conv_wgrad (split = 3, 3x3,
                                 tile of 1 or 2 k-steps of 16 pixels per wave group) */
 
+#define SPK_WGRAD_GROUPS 2048 /* spk_conv_wgrad, 1x1, split = 3: the kernel that gives a block 1 << (flags bits 12-13) = 2 or 4
+                                groups of 32 input channels (Cin % (32 * groups) == 0, WN 2 or 4, tile <= 64 pixels) */
+
 /* ---- convolutions --------------------------------------------------------------------------------- */
 
 /* nn.Conv2d weight [Cout][Cin][KH][KW] (scripts/model.py:12-15,105-110,233-234) -> MFMA fragment order
