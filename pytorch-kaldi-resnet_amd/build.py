@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspkhip.so")
 SOURCES = ["err.cpp", "conv_mfma.hip", "conv_wgrad.hip", "stem.hip", "bn.hip", "pool.hip", "gemm.hip", "head.hip",
-           "sgd.hip", "score.hip", "conv_split.hip", "conv_wgrad_split.hip", "pack.hip", "conv_ws.hip", "conv_pipe.hip", "conv_wgrad_pipe.hip", "conv_wgrad_1x1.hip"]
+           "sgd.hip", "score.hip", "conv_split.hip", "conv_wgrad_split.hip", "pack.hip", "conv_ws.hip", "conv_pipe.hip", "conv_wgrad_pipe.hip", "conv_wgrad_1x1.hip", "conv_wgrad_wm.hip"]
 
 
 def csrc_fingerprint():

@@ -17,7 +17,8 @@
 int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st);
 int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);
 int spk_launch_wgrad_pipe(const WgradArgs& a, int WN, hipStream_t st);
-int spk_launch_wgrad_1x1(const WgradArgs& a, int WN, int CG, hipStream_t st);   // conv_wgrad_1x1.hip: input-channel groups as "taps"      // conv_wgrad_pipe.hip: in-wave pipelined form        // conv_wgrad_split.hip: producer / consumer form
+int spk_launch_wgrad_1x1(const WgradArgs& a, int WN, int CG, hipStream_t st);
+int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st);                   // conv_wgrad_wm.hip: 2 x 2 wave layout (3x3)   // conv_wgrad_1x1.hip: input-channel groups as "taps"      // conv_wgrad_pipe.hip: in-wave pipelined form        // conv_wgrad_split.hip: producer / consumer form
 
 template <int NTAPS, int WK, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -302,10 +303,14 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.dy_amax = dy_amax; a.x_amax = x_amax;
     SPK_REQUIRE(split == 0 || split == 3 || ((split == 6 || split == 9) && ksize == 3),
                 "spk_conv_wgrad: split=%d (0; 3 = f16x3, any kernel size; 6 / 9 = bf16 terms, 3x3 only)", split);
-    if (flags & SPK_WGRAD_GROUPS) {       // 1x1, f16x3: bits 12-13 of flags = log2 of the input-channel groups per block
-        SPK_REQUIRE(split == 3 && ksize == 1, "spk_conv_wgrad: the grouped kernel exists for 1x1 in the f16x3 mode");
+    if (flags & SPK_WGRAD_GROUPS) {       // f16x3: bits 12-13 of flags = log2 of the input-channel groups per block
+        SPK_REQUIRE(split == 3, "spk_conv_wgrad: the grouped kernels exist in the f16x3 mode");
         const int cg = 1 << ((flags >> 12) & 3);
         a.flags = flags & SPK_IN_AFFINE_RELU;
+        if (ksize == 3) {                 // 3x3: two groups = the 2 x 2 wave layout
+            SPK_REQUIRE(cg == 2 && WN == 2, "spk_conv_wgrad: the 3x3 grouped kernel has 2 input-channel groups and WN = 2");
+            return spk_launch_wgrad_wm(a, (hipStream_t)stream);
+        }
         return spk_launch_wgrad_1x1(a, WN, cg, (hipStream_t)stream);
     }
     SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * WGRAD_NX, "spk_conv_wgrad: halo %dx%d exceeds the %d-pixel prefetch window",

@@ -1,0 +1,224 @@
+// 3x3 weight gradient, f16x3 operands, with the four waves of a block laid out 2 input-channel groups x 2 output-channel
+// groups (conv_wgrad_split_kernel lays them out 2 pixel halves x 2 output-channel groups).
+//
+// The staging of the weight gradient is VALU-bound and does not overlap the matrix instructions, so what
+// counts is staged elements per MFMA.  A block here owns 64 input x 64 output channels: it stages 64-channel X pixels
+// ([pixel][2 groups][terms][32 ch]) and the 64-channel dY tile once, and every wave runs ALL k-steps of the region on its
+// own 32 x 32 x 9-tap tile - 108 MFMAs per wave and region against 11 staging items per thread, where the pixel-split layout has
+// 54 against 9 (the dY tile was converted Cin/32 times, now Cin/64; the X tile Cout/64 times as before).  No cross-wave fold
+// at the end: a wave's accumulators are final.  Same MFMA order along the pixels of a region as the pixel-split layout
+// would use with WK = 1, but NOT the same summation order as WK = 2 (one accumulator instead of two partial ones), so
+// results agree with conv_wgrad_split_kernel to fp32 rounding, not bit for bit.
+#include "conv_wgrad.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+static __device__ __forceinline__ s16x8 tr_read8m(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+#define WM_NX 7      // X halo float4 per thread: halo_pix <= 16 * WM_NX pixels of 64 channels
+#define WM_ND 4      // dY float4 per thread: npix <= 16 * WM_ND
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    constexpr int NTAPS = 9, KS = 3, WN = 2;
+    constexpr int PX = 2 * 192;                           // X bytes per staged pixel: [2 groups][3-term pitch][32 ch fp16]
+    constexpr int PD = WN * 192 + 64;                     // dY bytes per pixel (as conv_wgrad_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int g, ci0, co0;                                      // block -> (region slice, channel groups), slices on one XCD
+    {
+        const int ncgi = a.Cin >> 6, M = ncgi * (a.Cout >> 6);
+        const int bid = blockIdx.x;
+        int m;
+        if ((a.nsplit & 7) == 0) {
+            const int k = bid >> 3;
+            m = k % M;
+            g = (k / M) * 8 + (bid & 7);
+        } else {
+            m = bid % M;
+            g = bid / M;
+        }
+        ci0 = (m % ncgi) * 64;
+        co0 = (m / ncgi) * 64;
+    }
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int npix = a.TH * a.TW;
+    const int nsteps_all = (npix + 15) >> 4;
+    const int npix_pad = nsteps_all << 4;
+    unsigned char* xs = ldsb;
+    unsigned char* dys = ldsb + halo_pix * PX;
+    const int flags = a.flags;
+    const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
+    const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
+
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int q16 = tid & 15;                             // this thread's float4 of the 64 channels of a pixel (X and dY alike)
+    f32x4 px[WM_NX], pd[WM_ND];
+    unsigned inx = 0, ind = 0;
+    const unsigned x_row = (unsigned)a.IW * a.Cin * 4u, x_px = (unsigned)a.Cin * 4u;
+    const unsigned d_row = (unsigned)a.OW * a.Cout * 4u, d_px = (unsigned)a.Cout * 4u;
+    const unsigned x_c = (unsigned)(ci0 + q16 * 4) * 4u, d_c = (unsigned)(co0 + q16 * 4) * 4u;
+    auto prefetch = [&](int region) {
+        int pt = region;
+        const int tx = pt % a.tiles_x;
+        pt /= a.tiles_x;
+        const int ty = pt % a.tiles_y;
+        const int b = pt / a.tiles_y;
+        const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+        const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
+        const char* xb = (const char*)(a.x + (size_t)b * a.IH * a.IW * a.Cin);
+        const char* db = (const char*)(a.dy + (size_t)b * a.OH * a.OW * a.Cout);
+        const unsigned x_safe = (unsigned)(oy0 * a.S) * x_row + (unsigned)(ox0 * a.S) * x_px + x_c;
+        const unsigned d_safe = (unsigned)oy0 * d_row + (unsigned)ox0 * d_px + d_c;
+        inx = 0;
+        ind = 0;
+#pragma unroll
+        for (int u = 0; u < WM_NX; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+            const int hx = p - hy * a.halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW && p < halo_pix;
+            if (ok) inx |= 1u << u;
+            const unsigned off = ok ? (unsigned)iy * x_row + (unsigned)ix * x_px + x_c : x_safe;
+            px[u] = *(const f32x4*)(xb + off);
+        }
+#pragma unroll
+        for (int u = 0; u < WM_ND; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+            const int lx = p - ly * a.TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            const bool ok = p < npix && oy < a.OH && ox < a.OW;
+            if (ok) ind |= 1u << u;
+            const unsigned off = ok ? (unsigned)oy * d_row + (unsigned)ox * d_px + d_c : d_safe;
+            pd[u] = *(const f32x4*)(db + off);
+        }
+    };
+    auto publish = [&]() {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (flags & SPK_IN_AFFINE_RELU) {
+            sc = *(const f32x4*)(a.in_scale + ci0 + q16 * 4);
+            sh = *(const f32x4*)(a.in_shift + ci0 + q16 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < WM_NX; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            f32x4 w = px[u];
+            if (flags & SPK_IN_AFFINE_RELU) {
+                w = w * sc + sh;
+                w[0] = fmaxf(w[0], 0.f);
+                w[1] = fmaxf(w[1], 0.f);
+                w[2] = fmaxf(w[2], 0.f);
+                w[3] = fmaxf(w[3], 0.f);
+            }
+            if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < halo_pix) {
+                uint2* dst = (uint2*)(xs + p * PX + (q16 >> 3) * 192) + (q16 & 7);
+                uint2 t0, t1;
+                split2h(w, sig_x, t0, t1);
+                dst[0] = t0;
+                dst[8] = t1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WM_ND; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            const f32x4 w = ((ind >> u) & 1) ? pd[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < npix_pad) {
+                uint2* dst = (uint2*)(dys + p * PD + (q16 >> 3) * 192) + (q16 & 7);
+                uint2 t0, t1;
+                split2h(w, sig_d, t0, t1);
+                dst[0] = t0;
+                dst[8] = t1;
+            }
+        }
+    };
+
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int col_off = (g16 & 1) * 32 + p4 * 8;
+    auto mma = [&](f32x16& c, const s16x8* af, const s16x8* bf) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1]), __builtin_bit_cast(f16x8, bf[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), c, 0, 0, 0);
+    };
+
+    int region = g;
+    if (region < a.nregions) prefetch(region);
+    for (; region < a.nregions; region += a.nsplit) {
+        __syncthreads();
+        publish();
+        __syncthreads();
+        if (region + a.nsplit < a.nregions) prefetch(region + a.nsplit);
+        for (int j = 0; j < nsteps_all; ++j) {
+            int xa[2], da[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int pix = j * 16 + 8 * h + 4 * blk + q;
+                const int pc = pix < npix ? pix : npix - 1;
+                const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
+                const int lx = pc - ly * a.TW;
+                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + wm * 192 + col_off;
+                da[blk] = pix * PD + wn * 192 + col_off;
+            }
+            s16x8 bf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[s] = tr_read8m(dys + da[0] + s * 64, dys + da[1] + s * 64);
+            s16x8 a0[2], a1[2];
+            auto load_a = [&](s16x8* af, int t) {
+                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) af[s] = tr_read8m(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+            };
+            load_a(a0, 0);
+#pragma unroll
+            for (int t = 0; t < NTAPS; t += 2) {
+                if (t + 1 < NTAPS) load_a(a1, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(acc[t], a0, bf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < NTAPS) load_a(a0, t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) mma(acc[t + 1], a1, bf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    const int r = lane & 31;
+    float* slab = a.partial + (size_t)g * NTAPS * a.Cin * a.Cout;
+    const float inv_x = 1.f / sig_x, inv_d = 1.f / sig_d;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            slab[((size_t)t * a.Cin + ci0 + wm * 32 + row) * a.Cout + co0 + wn * 32 + r] = acc[t][e] * inv_x * inv_d;
+        }
+}
+
+int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st) {
+    SPK_REQUIRE(a.KW == 3 && a.Cin % 64 == 0 && a.Cout % 64 == 0, "spk_conv_wgrad(2x2 waves): 3x3, Cin and Cout multiples of 64 (%d, %d)", a.Cin, a.Cout);
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 16 * WM_NX && a.TH * a.TW <= 16 * WM_ND, "spk_conv_wgrad(2x2 waves): tile %dx%d (halo %dx%d) exceeds the prefetch windows",
+                a.TH, a.TW, a.halo_h, a.halo_w);
+    const int npix_pad = ((a.TH * a.TW + 15) >> 4) << 4;
+    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 384 + (size_t)npix_pad * (2 * 192 + 64);
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
+    dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
+    hipLaunchKernelGGL(conv_wgrad_wm_kernel, grid, dim3(256), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_wgrad(2x2 waves)");
+    return 0;
+}

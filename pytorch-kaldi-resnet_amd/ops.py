@@ -132,6 +132,7 @@ PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
 # 0.75 vs 0.81 ms (64 channels) and 0.50 vs 0.54 ms (128 channels, against the wave-specialised kernel), nothing measurable per step
 PIPE_BNBWD = os.environ.get("SPK_PIPE_BNBWD", "0") == "1"
 GROUPED_1X1 = os.environ.get("SPK_WGRAD_1X1_GROUPS", "1") == "1"   # 1x1 weight gradients: input-channel groups as "taps"
+GROUPED_3X3 = os.environ.get("SPK_WGRAD_3X3_GROUPS", "1") == "1"   # 3x3 weight gradients: 2 x 2 (cin group x cout group) wave layout
 GROUPED_1X1_BLOCKS = int(os.environ.get("SPK_WGRAD_1X1_BLOCKS", "512"))
 PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
 PIPE_MAX_LDS = int(os.environ.get("SPK_PIPE_MAX_LDS", str(80 * 1024)))      # two halo tiles; <= 80 KiB keeps two blocks per CU
@@ -503,6 +504,11 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
         cg = 4 if Cin % 128 == 0 else (2 if Cin % 64 == 0 else 0)
         if cg and -(-(TH * TW) // 16) * 16 * (cg * 192 + WN * 192 + 64) > 80 * 1024:
             cg = 2 if cg == 4 else 0
+    # 3x3, f16x3: 2 input-channel groups x 2 output-channel groups of waves (csrc/conv_wgrad_wm.hip)
+    wm = (GROUPED_3X3 and not wgws and not wgp and split == 3 and ksize == 3 and WN == 2 and Cin % 64 == 0 and Cout % 64 == 0
+          and halo <= 112 and TH * TW <= 64 and halo * 384 + -(-(TH * TW) // 16) * 16 * 448 <= 80 * 1024)
+    if wm:
+        cg = 2
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else (GROUPED_1X1_BLOCKS if cg else None),
                                            cin_groups=cg or 1))
     nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
@@ -514,7 +520,8 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
+         label="conv_wgrad_wm_kernel" if wm
+         else ("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
          else ("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
          else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp
          else ("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (

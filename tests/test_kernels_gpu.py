@@ -247,8 +247,8 @@ def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
     same slab reduce => the weight gradients are bit-identical (with and without the fused BN + ReLU on X)."""
     from pytorch_kaldi_resnet_amd import tiling
     B, Cin, Cout, H, Wd, stride = shape
-    old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD)
-    ops.SPLIT = 3
+    old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD, ops.GROUPED_3X3)
+    ops.SPLIT, ops.GROUPED_3X3 = 3, False
     try:
         torch.manual_seed(11)
         x = torch.randn(B, H, Wd, Cin, device="cuda")
@@ -269,8 +269,18 @@ def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
                                           stride=stride, padding=1)
         err = (res[True][0].double().cpu() - ref).norm() / ref.norm()
         assert err < 1e-5, err
+        # the 2 x 2 wave layout (conv_wgrad_wm_kernel, the default where Cin and Cout are multiples of 64) sums the pixels of a
+        # region in one accumulator instead of two: same values to fp32 rounding, and as close to fp64 as the others
+        ops.WS_WGRAD, ops.PIPE_WGRAD, ops.GROUPED_3X3 = False, False, True
+        dwm = torch.empty(Cout, Cin, 3, 3, device="cuda")
+        ops.conv_wgrad(x, dy, dwm, 3, stride)
+        dwm2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+        ops.conv_wgrad(x, dy, dwm2, 3, stride, in_affine=(sc, sh), accumulate=True)
+        assert (dwm.double().cpu() - ref).norm() / ref.norm() < 1e-5
+        assert torch.allclose(dwm, res[False][0], rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
+        assert torch.allclose(dwm2, res[False][1], rtol=1e-4, atol=1e-6 * float((res[False][1] - 0.25).abs().max()))
     finally:
-        ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD = old
+        ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD, ops.GROUPED_3X3 = old
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 19, 45, 1), (2, 64, 64, 23, 41, 1), (3, 64, 128, 20, 27, 2), (2, 128, 128, 20, 75, 1),
