@@ -154,7 +154,8 @@ int spk_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
                  const float* res_shift, float* out, unsigned* mask_out, long long N, int C, int relu,
                  unsigned* amax_out /* optional: atomicMax of the float bits of |out| */, void* stream);
-/* backward; mask_mode 0: dz = dy, 1: dz = dy*(act > 0), 2: dz = dy*(raw*scale+shift > 0) */
+/* backward; mask_mode 0: dz = dy, 1: dz = dy*(act > 0), 2: dz = dy*(raw*scale+shift > 0), 3: as 1 with `act` pointing at the
+ * sign bits of the activated tensor ([pixel][C/32] words, spk_bn_apply mask_out) instead of the tensor */
 int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
                       void* stream);

@@ -10,7 +10,7 @@
 //                   -> bn_bwd_apply: draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
 #include "spk_common.h"
 
-enum { MASK_NONE = 0, MASK_ACT = 1, MASK_RAW = 2 };
+enum { MASK_NONE = 0, MASK_ACT = 1, MASK_RAW = 2, MASK_BITS = 3 };   // MASK_BITS: `act` holds sign bits, [pixel][C/32] words
 
 // ---- statistics of a plain [N][C] tensor ---------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
@@ -273,8 +273,16 @@ extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* s
 
 // ---- backward reduce: partial[blk][c] = (sum dz, sum dz*xhat), dz = dy * mask ---------------------------
 __device__ inline f32x4 bn_mask(f32x4 dy, int mode, const float* act, const float* raw_p, f32x4 rawv, f32x4 sc, f32x4 sh,
-                                long long off) {
-    if (mode == MASK_ACT) {
+                                long long off, int C = 0) {
+    if (mode == MASK_BITS) {
+        // sign bits written by spk_bn_apply (mask_out): one word per pixel and 32 channels; off = pixel * C + c
+        const int lg = 31 - __builtin_clz((unsigned)C);          // C is a power of two
+        const long long pix = off >> lg;
+        const int c = (int)(off & (C - 1));
+        const unsigned bits = ((const unsigned*)act)[pix * (C >> 5) + (c >> 5)] >> (c & 31);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dy[k] = ((bits >> k) & 1u) ? dy[k] : 0.f;
+    } else if (mode == MASK_ACT) {
         const f32x4 a = *(const f32x4*)(act + off);
 #pragma unroll
         for (int k = 0; k < 4; ++k) dy[k] = a[k] > 0.f ? dy[k] : 0.f;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const long long off = r * C + quad * 4;
         const f32x4 rv = *(const f32x4*)(raw + off);
         f32x4 d = *(const f32x4*)(dy + off);
-        d = bn_mask(d, mode, act, raw, rv, sc, sh, off);
+        d = bn_mask(d, mode, act, raw, rv, sc, sh, off, C);
         const f32x4 xh = (rv - mu) * is;
         s += d;
         ss += d * xh;
@@ -338,8 +346,8 @@ extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float*
                                  void* stream) {
     SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && partial, "spk_bn_bwd_reduce: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_reduce: N=%lld C=%d", N, C);
-    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spk_bn_bwd_reduce: mask_mode=%d", mask_mode);
-    SPK_REQUIRE(mask_mode != MASK_ACT || act, "spk_bn_bwd_reduce: MASK_ACT needs the activated tensor");
+    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_reduce: mask_mode=%d", mask_mode);
+    SPK_REQUIRE((mask_mode != MASK_ACT && mask_mode != MASK_BITS) || act, "spk_bn_bwd_reduce: MASK_ACT / MASK_BITS need the activated tensor / its sign bits");
     const int nb = spk_bn_stats_blocks(N, C);
     const int rpb = (int)((N + nb - 1) / nb);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean, invstd, scale,
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const long long off = i * 4;
         const f32x4 rv = *(const f32x4*)(raw + off);
         f32x4 d = *(const f32x4*)(dy + off);
-        d = bn_mask(d, mode, act, raw, rv, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), off);
+        d = bn_mask(d, mode, act, raw, rv, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), off, C);
         const f32x4 xh = (rv - *(const f32x4*)(mean + c)) * *(const f32x4*)(invstd + c);
         const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
         const f32x4 o = k1 * (d - m1 - xh * m2);
@@ -434,8 +442,8 @@ extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* 
                                 long long N, int C, int mask_mode, unsigned* amax_out, void* stream) {
     SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && coef && draw, "spk_bn_bwd_apply: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_apply: N=%lld C=%d", N, C);
-    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
-    SPK_REQUIRE(mask_mode != MASK_ACT || act, "spk_bn_bwd_apply: MASK_ACT needs the activated tensor");
+    SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
+    SPK_REQUIRE((mask_mode != MASK_ACT && mask_mode != MASK_BITS) || act, "spk_bn_bwd_apply: MASK_ACT / MASK_BITS need the activated tensor / its sign bits");
     const long long nquads = N * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
                        invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out);

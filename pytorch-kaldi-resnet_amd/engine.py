@@ -11,7 +11,7 @@ downsample's raw output).  Backward recomputes relu(bn1(raw1)) on the fly inside
 import torch
 
 from . import ops
-from .hip import MASK_ACT, MASK_NONE, MASK_RAW
+from .hip import MASK_ACT, MASK_BITS, MASK_NONE, MASK_RAW
 
 
 class _Conv:
@@ -128,6 +128,7 @@ class Engine:
         import os
         self.use_sign_masks = os.environ.get("SPK_SIGN_MASKS", "1") == "1"
         self.fuse_apply_min_c = int(os.environ.get("SPK_FUSE_APPLY_MINC", "0"))   # experiment knob: skip the fusion below C channels
+        self.fuse_apply_max_c = int(os.environ.get("SPK_FUSE_APPLY_MAXC", "1000000"))   # ... and above
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def _all_convs(self):
@@ -447,7 +448,7 @@ class Engine:
                     if rec.get("xmask") is not None:
                         bnb = bnb + (rec["xmask"],)                     # sign bits of x instead of x itself
             res_amax, draw_amax = take(), take()
-            if self.fuse_bn_apply and c.stride == 1 and c.cout >= self.fuse_apply_min_c:
+            if self.fuse_bn_apply and c.stride == 1 and self.fuse_apply_min_c <= c.cout <= self.fuse_apply_max_c:
                 if g_part is None:
                     g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
                 est = take() if f16 else None
@@ -470,15 +471,26 @@ class Engine:
                 if last:
                     dz = dzb
             else:
+                lazy_dz = False
                 if last:
-                    draw = ops.bn_backward(g, raw, out, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_ACT,
-                                           dz_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax)
-                    dz = g                                              # dout now holds dz
+                    # separate BatchNorm-backward pass (then a plain, pipelined data gradient).  With sign masks it reads the
+                    # bits instead of the block output, and with an identity shortcut dz is not stored: the first conv's
+                    # data-gradient epilogue re-forms it from dout and the bits (as in the fused form above)
+                    bits = rec.get("mask")
+                    lazy_dz = b.ds is None and bits is not None and n > 1
+                    draw = ops.bn_backward(g, raw, bits if bits is not None else out, bn.t4, bn.h.weight.data, bn.h.weight.grad,
+                                           bn.h.bias.grad, MASK_BITS if bits is not None else MASK_ACT,
+                                           dz_out=None if lazy_dz else g, accumulate=acc, partial=g_part, amax_out=draw_amax)
+                    dz = None if lazy_dz else g                         # (dout now holds dz)
                 else:
                     draw = ops.bn_backward(g, raw, None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_RAW,
                                            draw_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax)
-                res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                     in_amax=draw_amax if f16 else None, out_amax=res_amax)
+                if add_dz and dz is None and rec.get("mask") is not None:
+                    res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
+                                         in_amax=draw_amax if f16 else None, out_amax=res_amax)
+                else:
+                    res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb,
+                                         in_amax=draw_amax if f16 else None, out_amax=res_amax)
             g, g_part = res if bnb is not None else (res, None)
             g_amax = res_amax
             self._wgrad(inp, draw, c.h.weight.grad, c.k, c.stride, in_affine=in_aff, accumulate=acc,

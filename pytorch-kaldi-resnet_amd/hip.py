@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SPK_LIB", os.path.join(_HERE, "libspkhip.so"))   # SP
 IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD, IN_BNBWD, CONV_WS = 1, 2, 4, 8, 16, 32, 64, 128
 CONV_PIPE = 1024
 WGRAD_GROUPS = 2048        # spk_conv_wgrad flags: 1x1 f16x3 kernel with 1 << (bits 12-13) input-channel groups per block
-MASK_NONE, MASK_ACT, MASK_RAW = 0, 1, 2
+MASK_NONE, MASK_ACT, MASK_RAW, MASK_BITS = 0, 1, 2, 3
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
