@@ -50,6 +50,9 @@ def mfma_peak(kernel_label):
         terms = int(inner[4])
     elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 5:
         terms = int(inner[3])
+    elif kernel_label.startswith(("conv_pipe_kernel", "conv_wgrad_wm_kernel", "conv_wgrad_1x1_kernel", "conv_wgrad_pipe_kernel",
+                                  "conv_wgrad_ws_kernel")):
+        terms = 3           # these forms exist for the f16x3 operand mode only
     if terms:
         return PEAK_BF16_MFMA_TFLOPS / terms, "%s dense peak / %d cross products per fp32 multiply-add" % (
             "fp16" if terms == 3 else "bf16", terms)
