@@ -60,6 +60,8 @@ CONV_CASES = [
     (2, 64, 64, 7, 9, 1, 1),
     (2, 256, 256, 10, 38, 3, 1),
     (1, 256, 256, 5, 3, 3, 1),
+    (2, 128, 256, 10, 19, 1, 2),    # 1x1: four input-channel groups per block (conv_wgrad_1x1_kernel), strided
+    (2, 256, 64, 9, 11, 1, 1),
 ]
 
 
