@@ -2,15 +2,23 @@
 """Headline benchmark: training throughput of the ResNet-34 + AAM-softmax hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1 without WORLD_SIZE in the environment: this process spawns its N ranks itself (python -m torch.distributed.run
+  --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...) BEFORE touching the GPU, relays rank 0's
+  JSON line and exits with the children's code - the reference spawns its own ranks too (scripts/train_resnet.py:122-128).
+  Launched by torch.distributed.run (RANK / WORLD_SIZE set) it is one of the ranks.
 
 A "step" is one full training iteration of BASELINE.json configs[1] on one batch of synthetic input that is
 already resident in HBM: forward (train-mode BN) + AAM margin + cross-entropy + hand-written backward +
 fused SGD (+ overlapped RCCL gradient all-reduce when N > 1; per-GPU batch fixed at 256 = weak scaling).
 Prints ONE JSON line (see the repo contract) with two extra objects:
-  roofline     - dominant kernel (by total device time in an instrumented pass of the same steps), its
-                 algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch
-                 stream, against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)
+  roofline     - dominant kernel (by total device time in an instrumented pass of the same steps): its algorithmic
+                 FLOPs and bytes per launch / average launch duration measured with HIP events on the launch stream,
+                 priced against BOTH ceilings of MI355X_MICROARCH.md - the dense matrix peak of its operand mode (fp16 /
+                 bf16 2.5 PFLOP/s divided by the matrix instructions per fp32 multiply-add; fp32 157.3 TFLOP/s) and
+                 8 TB/s of HBM; the larger fraction names the binding one
+  f16_window   - (f16x3 mode) counters of the operand-scale windows of one full-size step: staged values that would
+                 saturate fp16 (must be 0: every scale comes from an absmax or a rigorous bound) and the share that
+                 falls below the two-term window (carried with 11 instead of 22 significand bits)
   cpu_baseline - the CPU oracle (oracle/spk_oracle.py, a torch-CPU port of the reference path) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N = 1 only): 2 warm-ups + median of 5
                  steps of the C2-micro (bs 32, T = 300) and the C1 shape (bs 32, T = 200), train step and predict
@@ -21,6 +29,9 @@ Prints ONE JSON line (see the repo contract) with two extra objects:
      c1  ResNet-34 + AAM, 10 speakers, bs 32, 200 frames       (the run_aam_cpu.sh shape, on the GPU)
      c4  ResNet-101 + AAM, 5994 speakers, one chunk length per step in [200, 400], bs 256 (per-length hipGraph cache)
      c5  eval-mode embedding extraction (predict), bs 512, 300 frames
+  --ingest   loader-inclusive throughput: a seeded fbank ark is written once, then every step's batch comes from the native
+             reader (libspkio: pread of the cropped frames on --ingest-threads threads into a pinned ring) -> H2D copy on a
+             copy stream -> the same graph replay; reports utt/s and its ratio to the resident-input figure of the same run
 """
 import argparse
 import json
@@ -87,6 +98,11 @@ def parse():
     ap.add_argument("--no-eer", action="store_true")
     ap.add_argument("--config", choices=["c1", "c2", "c4", "c5"], default=None,
                     help="BASELINE.json configuration preset (c2 = headline = the defaults)")
+    ap.add_argument("--ingest", action="store_true",
+                    help="also time the loader-inclusive step: seeded ark -> libspkio reader -> pinned ring -> H2D -> graph replay")
+    ap.add_argument("--ingest-utts", type=int, default=4096, help="utterances in the synthetic ark of --ingest")
+    ap.add_argument("--ingest-threads", type=int, default=8, help="reader threads of --ingest")
+    ap.add_argument("--no-f16-window", action="store_true", help="skip the operand-scale window counters (f16x3 mode)")
     a = ap.parse_args()
     if a.config == "c1":
         a.batch, a.frames, a.speakers = 32, 200, 10
@@ -244,6 +260,46 @@ def embedding_parity(dev):
     return float((1.0 - cos).max())
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh children - one process per GPU,
+    torch.distributed.run on 127.0.0.1 - before this process has touched the GPU (it never does), relay their output
+    (rank 0 prints the JSON line to the inherited stdout) and leave with their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def write_ingest_ark(d, n_utts, frames, nspk, seed):
+    """Synthetic training corpus of --ingest: n_utts utterances x (frames + 0..31) frames x 80 mel, N(0,1), in one `FM `
+    ark + scp (offset form) + utt2spkid, written with the package's own kaldi_io writer."""
+    import numpy as np
+    from pytorch_kaldi_resnet_amd import kaldi_io
+    rs = np.random.RandomState(seed)
+    ark = os.path.join(d, "feats.ark")
+    scp, u2s = [], []
+    with open(ark, "wb") as f:
+        for i in range(n_utts):
+            T = frames + int(rs.randint(0, 32))
+            mat = rs.standard_normal((T, FEAT)).astype(np.float32)
+            utt = "utt%06d" % i
+            off = kaldi_io.write_mat(f, mat, key=utt)
+            scp.append("%s %s:%d" % (utt, ark, off))
+            u2s.append("%s %d" % (utt, i % nspk))
+    open(os.path.join(d, "train.scp"), "w").write("\n".join(scp) + "\n")
+    open(os.path.join(d, "utt2spkid"), "w").write("\n".join(u2s) + "\n")
+    return os.path.join(d, "train.scp"), os.path.join(d, "utt2spkid"), os.path.getsize(ark)
+
+
 def log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
     sys.stderr.flush()
@@ -259,8 +315,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)          # never returns; nothing above has initialised the GPU
     # rehearsal hooks (one-GPU box): SPK_FORCE_DEVICE pins every rank to one device, SPK_DIST_BACKEND=gloo replaces
     # RCCL so the N > 1 control flow can be exercised where only one GPU exists.  Never set by the driver.
     if "SPK_FORCE_DEVICE" in os.environ:
@@ -413,6 +469,69 @@ def main():
             raise SystemExit("bench: the replayed hipGraph uses stale packed conv weights %s - not a valid training step" % bad)
     log("timed region done: %.3f s for %d steps (host enqueue %.1f ms/step)" % (dt, args.steps, t_host / args.steps * 1e3))
 
+    ingest = None
+    if args.ingest and args.mode == "train" and var_x is None:
+        # Loader-inclusive step (reference scripts/train_resnet.py:307-313: loader -> pinned H2D -> step): every rank reads
+        # its own seeded ark through libspkio (pread of the cropped frames on a thread pool into a pinned ring, guarded by
+        # copy events), the copy runs on the loader's copy stream under the previous step's kernels, then the same replay.
+        import tempfile
+        import contextlib as _cl
+        from pytorch_kaldi_resnet_amd.ingest import NativeTrainLoader
+        d = tempfile.mkdtemp(prefix="spk_ingest_r%d_" % rank)
+        t_w = time.perf_counter()
+        scp, u2s, ark_bytes = write_ingest_ark(d, args.ingest_utts, args.frames, nspk, 99 + rank)
+        log("ingest: wrote %d utterances, %.0f MB ark in %.1f s" % (args.ingest_utts, ark_bytes / 1e6, time.perf_counter() - t_w))
+        with _cl.redirect_stdout(sys.stderr):
+            loader = NativeTrainLoader(scp, u2s, args.frames, args.batch, rank=0, world=1, seed=5, threads=args.ingest_threads,
+                                       drop_last=True, prefetch=3, device=str(dev))
+
+        def batches():
+            ep = 0
+            while True:
+                loader.set_epoch(ep)
+                ep += 1
+                for xb, yb in loader:
+                    yield xb, yb
+        it = batches()
+
+        def ingest_step():
+            xb, yb = next(it)
+            if graphed is not None:
+                lossi, _, _ = graphed(xb, yb, red.on_stage_done if world > 1 else None)
+            else:
+                opt.zero_grad(set_to_none=True)
+                lossi, _, _ = eng.loss_and_grad(xb, yb, red.on_stage_done if world > 1 else None)
+            red.finish()
+            opt.step()
+            return lossi
+        for _ in range(max(2, args.warmup)):
+            ingest_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ingest_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dti = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dti], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dti = float(t)
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+        ingest = {"value": round(args.batch * world * args.steps / dti, 2), "unit": "utt/s",
+                  "ms_per_step": round(dti / args.steps * 1e3, 3),
+                  "ratio_to_resident_input": round(dt / dti, 4), "reader_threads": args.ingest_threads,
+                  "path": "seeded FM ark (%d utts x %d..%d frames x %d mel, %.0f MB, page cache) -> libspkio pread+crop+transpose -> "
+                          "pinned ring (5 slots, copy-event guarded) -> H2D on a copy stream -> step" % (
+                              args.ingest_utts, args.frames, args.frames + 31, FEAT, ark_bytes / 1e6)}
+        log("ingest-inclusive: %.1f utt/s (%.3f of the resident-input rate)" % (ingest["value"], ingest["ratio_to_resident_input"]))
+
     roofline = None
     if rank == 0 and not args.no_roofline and args.mode == "train":
         # instrumented pass: same steps, every launch bracketed by HIP events on its launch stream; the side stream
@@ -538,10 +657,17 @@ def main():
                 "f32 (operands as 2 fp16 terms of value x 2^k, 3 cross products, f32 accumulate)" if ops.SPLIT == 3 else
                 "f32 (operands as 3 exact bf16 terms, %d cross products, f32 accumulate)" % ops.SPLIT),
             "data": "synthetic",
-            "config": {"workload": "%s: %s + AAM-softmax (m 0.2, s 30), %d speakers, "
-                                   "%s x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
-                                   % ("BASELINE configs[1]" if headline else "non-headline case", arch_name, nspk,
-                                      frames_desc, FEAT, args.batch),
+            "config": {"workload": ("%s: %s + AAM-softmax (m 0.2, s 30), %d speakers, "
+                                    "%s x %d fbank, per-GPU batch %d, fwd+CE+bwd+SGD(0.9, wd 5e-4)"
+                                    % ("BASELINE configs[1]" if headline else (
+                                        "BASELINE configs[3] shape on %d GPU(s)" % world if (args.arch == "resnet101" and nspk == 5994
+                                                                                           and var_x is not None)
+                                        else "non-headline case"), arch_name, nspk, frames_desc, FEAT, args.batch))
+                       if args.mode == "train" else
+                       ("%s: eval-mode predict() of %s (BatchNorm folded into the conv epilogues), %s x %d fbank, batch %d, inputs "
+                        "resident in HBM; the ark -> reader -> writer pipeline around it is tools/c5_extract.py"
+                        % ("BASELINE configs[4] kernel path" if (args.arch == "resnet34" and args.batch == 512) else "non-headline case",
+                           arch_name, frames_desc, FEAT, args.batch)),
                        "global_batch": gb, "frames": args.frames if var_x is None else list(args.frames_range),
                        "feat_dim": FEAT, "speakers": nspk,
                        "parallelism": "dp%d" % world,
@@ -554,7 +680,7 @@ def main():
             "graph_replay_repacks_weights": repack_ok, "eer": eer,
             "kernel_launches_per_step": (sum(v["launches_per_step"] for v in roofline["all_kernels"].values())
                                          if roofline else None),
-            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native, "ingest": ingest,
             "embedding_cosine_delta_vs_oracle": parity,
         }
         print(json.dumps(out))

@@ -47,8 +47,18 @@ const char* spk_last_error(void);
                                 tiles in LDS; with SPK_IN_BNBWD: in_mask given, MT*NT <= 4) and spk_conv_wgrad (split = 3, 3x3,
                                 tile of 1 or 2 k-steps of 16 pixels per wave group) */
 
-#define SPK_WGRAD_GROUPS 2048 /* spk_conv_wgrad, 1x1, split = 3: the kernel that gives a block 1 << (flags bits 12-13) = 2 or 4
-                                groups of 32 input channels (Cin % (32 * groups) == 0, WN 2 or 4, tile <= 64 pixels) */
+#define SPK_WGRAD_GROUPS 2048 /* spk_conv_wgrad, split = 3: 1x1: the kernel that gives a block 1 << (flags bits 12-13) = 2 or 4
+                                groups of 32 input channels (Cin % (32 * groups) == 0, WN 2 or 4, tile <= 64 pixels); 3x3: the
+                                2 x 2 (input-channel group x output-channel group) wave layout (groups = 2, WN = 2) */
+
+/* f16 pair tensors (split = 3).  A tensor with the shape and addressing of an fp32 NHWC tensor in which every aligned group of
+ * four floats (16 bytes) holds [4 x fp16 high term][4 x fp16 low term] of value * sigma, sigma = the power of two that takes
+ * the float whose bits the tensor's scale slot holds into [2^14, 2^15).  The slot holds a RIGOROUS upper bound of the tensor's
+ * absmax, known before the producer runs (spk_bn_bwd_finalize est_out).  Producers: spk_bn_bwd_apply(pair_scale), and the side
+ * output of a fused BatchNorm-backward data gradient (SPK_SIDE_PRESPLIT).  Consumers stage 16-byte groups by plain copy. */
+#define SPK_IN_PRESPLIT (1 << 14)    /* spk_conv_mfma: `in` is an f16 pair tensor scaled by the sigma of *in_amax (plain input only) */
+#define SPK_SIDE_PRESPLIT (1 << 15)  /* spk_conv_mfma + SPK_IN_BNBWD: side_draw leaves as an f16 pair tensor (scale: *in_amax) */
+#define SPK_DY_PRESPLIT (1 << 16)    /* spk_conv_wgrad: `dy` is an f16 pair tensor scaled by the sigma of *dy_amax */
 
 /* ---- convolutions --------------------------------------------------------------------------------- */
 
@@ -58,7 +68,7 @@ int spk_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, 
 /* the same weights for the split operand modes of spk_conv_mfma: split = 6 or 9: every weight as three bf16 terms whose sum
  * is the fp32 value, [tap][K/16][term][N/32][64][8 bf16] = 6 bytes per weight; split = 3: a 16-byte header (word 0 = float
  * bits of max|w|) followed by w * sigma as two fp16 terms in the same order (4 bytes per weight), sigma = the power of two
- * that puts max|w| in [2^8, 2^9) - spk_conv_mfma reads the header and derives the same sigma */
+ * that puts max|w| in [2^14, 2^15) - spk_conv_mfma reads the header and derives the same sigma */
 int spk_pack_conv_weight_split(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int transpose, int split,
                                void* stream);
 /* every convolution of the network in one launch: `jobs` is a device array of njobs 48-byte entries
@@ -82,12 +92,15 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * three bf16 terms while staged / packed (wpk from spk_pack_conv_weight_split) and the 6 most significant (or all 9) cross
  * terms multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - inputs, outputs and measured accuracy are fp32
  * (planes are then 16 channels: Cin % (16*kc) == 0).
- * split = 3 ("f16x3"): operands as two fp16 terms of value * sigma, sigma a power of two (weights: from max|w| at pack time;
- * staged input: 2^6 when in_amax is NULL - activations - else 2^(8 - exponent) of the float whose bits *in_amax holds,
- * the tensor's absmax or an upper estimate of it: gradients), three cross products on v_mfma_f32_32x32x16_f16, fp32
- * accumulation, accumulators scaled back by 1/(sigma_in * sigma_w).  Measured accuracy = the fp32 instruction's
- * (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the launch atomically maxes the float
- * bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume those tensors.
+ * split = 3 ("f16x3", 3x3 and 1x1): operands as two fp16 terms of value * sigma, sigma a power of two (weights: from max|w| at
+ * pack time; staged input: 2^(14 - exponent) of the float whose bits *in_amax holds - REQUIRED: the absmax of the staged
+ * values, written by the kernel that produced the tensor, or a rigorous upper bound of it (spk_bn_finalize est_out for a fused
+ * input BatchNorm+ReLU, spk_bn_bwd_finalize est_out for a fused BatchNorm backward) - so that the largest staged magnitude
+ * lands in [2^14, 2^15) and nothing can saturate), three cross products on v_mfma_f32_32x32x16_f16, fp32 accumulation,
+ * accumulators scaled back by 1/(sigma_in * sigma_w).  Values below bound * 2^-17 lose the low term (carried with 11 bits).
+ * Measured accuracy = the fp32 instruction's (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the
+ * launch atomically maxes the float bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume
+ * those tensors (side_amax records the true absmax also when side_draw leaves as an f16 pair tensor).
  * flags: the SPK_* bits above. */
 int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
                   const float* epi_scale, const float* epi_shift, const float* epi_add, const float* in_raw,
@@ -113,10 +126,11 @@ size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
 int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate, void* stream);
 int spk_conv_wgrad(const float* x, const float* dy, float* dw, float* partial, const float* in_scale,
                    const float* in_shift, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksize, int stride,
-                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, int split /* 0, or 6 / 9 = bf16-split operands,
-                   3 = fp16 two-term operands (3x3 only), see spk_conv_mfma */, const unsigned* dy_amax /* split 3: float bits
-                   of absmax(dy), fixes the dY operand scale */, const unsigned* x_amax /* the same for the (transformed) x
-                   operand: its absmax or an upper estimate (spk_affine_estimate) */, void* stream);
+                   int TH, int TW, int WN, int nsplit, int flags, int accumulate, int split /* 0, or 6 / 9 = bf16-split operands
+                   (3x3 only), 3 = fp16 two-term operands (3x3 and 1x1), see spk_conv_mfma */, const unsigned* dy_amax /* split 3,
+                   required: float bits of absmax(dy) or of an upper bound: fixes the dY operand scale (the scale slot of dy when
+                   SPK_DY_PRESPLIT) */, const unsigned* x_amax /* split 3, required: the same for the (transformed) x operand:
+                   its absmax or a bound (spk_bn_finalize est_out / spk_affine_estimate) */, void* stream);
 
 /* Stem Conv2d(1,32,3,1,1,bias=False) (scripts/model.py:210,249): x [B][F][T] -> out [B][F][T][32];
  * stats (EPI_STATS): [spk_stem_fwd_blocks()][32][2]. */
@@ -161,17 +175,29 @@ int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const
                       void* stream);
 int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws,
-                        const unsigned* amax_in, unsigned* est_out /* optional: the spk_bnbwd_estimate value, per channel, by
-                        atomicMax - saves that launch */, void* stream);
+                        const unsigned* amax_in, const unsigned* raw_amax, const float* mean, unsigned* est_out /* optional
+                        (needs the three before it): the spk_bnbwd_estimate bound, per channel, by atomicMax - saves that launch */,
+                        void* stream);
 int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,
                      int C, int mask_mode, unsigned* amax_out /* optional: atomicMax of the float bits of |draw| */,
-                     void* stream);
-/* operand-scale hand-offs of the f16x3 mode (see spk_conv_mfma): *slot = max(*slot, bits(max|x|)); and the upper estimate
- * max_c |k1_c| (A + |m1_c| + 8 |m2_c|) of the values a fused BatchNorm-backward data gradient stages, from the coefficient
- * rows coef[3][C] of spk_bn_bwd_finalize and A = the float whose bits *amax_in holds (absmax of the incoming gradient) */
+                     const unsigned* pair_scale /* optional: draw is written as an f16 pair tensor (see SPK_IN_PRESPLIT) scaled
+                     by the sigma of *pair_scale - the est_out slot of spk_bn_bwd_finalize */, void* stream);
+/* operand-scale hand-offs of the f16x3 mode (see spk_conv_mfma): *slot = max(*slot, bits(max|x|)); and the RIGOROUS upper bound
+ * max_c |k1_c| (A + |m1_c| + (R + |mean_c|) invstd_c |m2_c|) (1 + 2^-16) of the values k1 (dz - m1 - xhat m2) of a BatchNorm
+ * backward - staged by a fused data gradient or written as an f16 pair tensor - from the coefficient rows coef[3][C] of
+ * spk_bn_bwd_finalize, the BatchNorm's mean / invstd rows, A = the float in *amax_in (absmax of the incoming gradient, so
+ * |dz| <= A) and R = the float in *raw_amax (absmax of the raw tensor, so |xhat| <= (R + |mean|) invstd) */
 int spk_absmax(const float* x, unsigned* slot, long long n, void* stream);
-int spk_bnbwd_estimate(const float* coef, int C, const unsigned* amax_in, unsigned* est, void* stream);
+int spk_bnbwd_estimate(const float* coef, const float* mean, const float* invstd, int C, const unsigned* amax_in,
+                       const unsigned* raw_amax, unsigned* est, void* stream);
+/* diagnostics of the f16x3 windows (debug / tests, never on the training path): counts[0] += values looked at, [1] += values
+ * that saturate fp16 under the slot's scale (must stay 0), [2] += values whose low term is an fp16 subnormal (carried with 11
+ * significand bits), [3] += values whose high term is subnormal.  The values are x (n floats, n % 4 == 0), or
+ * max(x*scale[c]+shift[c], 0) with c = index % C when scale / shift are given, or - pairs != 0 - the stored terms of an f16
+ * pair tensor. */
+int spk_f16_window_count(const float* x, const float* scale, const float* shift, long long n, int C, const unsigned* slot,
+                         int pairs, unsigned long long* counts /*[4], device*/, void* stream);
 /* upper bound of |relu(raw * scale_c + shift_c)| from A = absmax(raw): max_c |scale_c| * A + max_c |shift_c| - the operand
  * scale input of a convolution / weight gradient that applies BatchNorm+ReLU while staging (SPK_IN_AFFINE_RELU) */
 int spk_affine_estimate(const float* scale, const float* shift, int C, const unsigned* amax_in, unsigned* est, void* stream);

@@ -356,13 +356,22 @@ extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float*
     return 0;
 }
 
+// Upper bound of |k1 (dz - m1 - xhat m2)| over one channel, for |dz| <= A and |raw| <= R: |xhat| <= (R + |mean|) invstd.
+// The value is evaluated in fp32 as k1 * (dz - m1 - ((raw - mean) * invstd) * m2): five roundings of relative size 2^-24,
+// covered (with the roundings of this expression) by the factor 1 + 2^-16.
+__device__ inline float bnbwd_bound(float k1, float m1, float m2, float mean, float invstd, float A, float R) {
+    const float xh = (R + fabsf(mean)) * fabsf(invstd);
+    return fabsf(k1) * (A + fabsf(m1) + xh * fabsf(m2)) * (1.f + 1.52587890625e-05f);
+}
+
 // ---- backward finalize: dgamma, dbeta and the apply coefficients coef[3][C] = (gamma*invstd, dbeta/n, dgamma/n)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restrict__ partial, int nblk, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef, int accumulate,
-                                                              const unsigned* __restrict__ amax_in, unsigned* __restrict__ est_out) {
+                                                              const unsigned* __restrict__ amax_in, const unsigned* __restrict__ raw_amax,
+                                                              const float* __restrict__ mean, unsigned* __restrict__ est_out) {
     __shared__ double red[8][32][2];
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
@@ -382,10 +391,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
         coef[ch] = k1;
         coef[C + ch] = m1;
         coef[2 * C + ch] = m2;
-        // f16x3 hand-off: upper estimate of the values k1 (dz - m1 - xhat m2) the fused data gradient will stage (see
-        // spk_bnbwd_estimate), maximum over channels by atomicMax
+        // f16x3 hand-off: RIGOROUS upper bound of the values k1 (dz - m1 - xhat m2) the BatchNorm backward produces (staged by the
+        // fused data gradient, or written as f16 pairs by spk_bn_bwd_apply), maximum over channels by atomicMax.
+        // |dz| <= A = absmax of the incoming gradient, |xhat| = |raw - mean| invstd <= (R + |mean|) invstd with R = absmax(raw),
+        // both slots complete before this launch; bnbwd_bound() adds the rounding slack of the fp32 evaluation.
         if (est_out) {
-            const float e = SPK_F16_EST_HEADROOM * fabsf(k1) * (__uint_as_float(*amax_in) + fabsf(m1) + 8.f * fabsf(m2));
+            const float e = bnbwd_bound(k1, m1, m2, mean[ch], invstd[ch], __uint_as_float(*amax_in), __uint_as_float(*raw_amax));
             const unsigned bits = __float_as_uint(e);
             if (bits > __hip_atomic_load(est_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(est_out, bits);
         }
@@ -394,19 +405,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
 
 extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate,
-                                   double* ws, const unsigned* amax_in, unsigned* est_out, void* stream) {
+                                   double* ws, const unsigned* amax_in, const unsigned* raw_amax, const float* mean,
+                                   unsigned* est_out, void* stream) {
     SPK_REQUIRE(partial && gamma && invstd && dgamma && dbeta && coef, "spk_bn_bwd_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_bwd_finalize: bad sizes");
+    SPK_REQUIRE(!est_out || (amax_in && raw_amax && mean), "spk_bn_bwd_finalize: est_out needs amax_in, raw_amax and mean");
     hipStream_t st = (hipStream_t)stream;
     if (spk_bn_finalize_workspace(nblk, C)) {
         SPK_REQUIRE(ws, "spk_bn_bwd_finalize: %d partial rows need the fp64 workspace", nblk);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
         SPK_LAUNCH_CHECK("spk_bn_bwd_finalize(fold)");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
-                           gamma, invstd, dgamma, dbeta, coef, accumulate, amax_in, est_out);
+                           gamma, invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
-                           invstd, dgamma, dbeta, coef, accumulate, amax_in, est_out);
+                           invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out);
     }
     SPK_LAUNCH_CHECK("spk_bn_bwd_finalize");
     return 0;
@@ -418,9 +431,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef,
                                                            float* __restrict__ draw, float* __restrict__ dz_out,
-                                                           long long nquads, int C, int mode, unsigned* __restrict__ amax_out) {
+                                                           long long nquads, int C, int mode, unsigned* __restrict__ amax_out,
+                                                           const unsigned* __restrict__ pair_scale) {
     const int cmask = C - 1;
     float mx = 0.f;
+    const float sig = pair_scale ? spk_sigma_from_amax_bits(*pair_scale) : 1.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
         const int c = (int)((i * 4) & cmask);
         const long long off = i * 4;
@@ -431,7 +446,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
         const f32x4 o = k1 * (d - m1 - xh * m2);
         if (dz_out) *(f32x4*)(dz_out + off) = d;
-        *(f32x4*)(draw + off) = o;
+        if (pair_scale) {      // f16 pair tensor: converted here once, staged by plain copy in the data and weight gradients
+            uint2 t0, t1;
+            split2h(o, sig, t0, t1);
+            *(f32x4*)(draw + off) = spk_pair_pack(t0, t1);
+        } else
+            *(f32x4*)(draw + off) = o;
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
     if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(draw): the operand scale of its f16x3 consumers
@@ -439,14 +459,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                                 const float* scale, const float* shift, const float* coef, float* draw, float* dz_out,
-                                long long N, int C, int mask_mode, unsigned* amax_out, void* stream) {
+                                long long N, int C, int mask_mode, unsigned* amax_out, const unsigned* pair_scale, void* stream) {
     SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && coef && draw, "spk_bn_bwd_apply: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_apply: N=%lld C=%d", N, C);
     SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
     SPK_REQUIRE((mask_mode != MASK_ACT && mask_mode != MASK_BITS) || act, "spk_bn_bwd_apply: MASK_ACT / MASK_BITS need the activated tensor / its sign bits");
     const long long nquads = N * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
-                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out);
+                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out, pair_scale);
     SPK_LAUNCH_CHECK("spk_bn_bwd_apply");
     return 0;
 }
@@ -472,17 +492,18 @@ extern "C" int spk_absmax(const float* x, unsigned* slot, long long n, void* str
     return 0;
 }
 
-// Upper estimate of max |k1 (dz - m1 - xhat m2)| - the values a fused BatchNorm-backward data gradient stages - from the
-// coefficient rows [k1, m1, m2][C] and A = absmax of the incoming gradient (|dz| <= A): max_c |k1_c| (A + |m1_c| + 8 |m2_c|).
-// |xhat| <= 8 is a heuristic, so the estimate is multiplied by SPK_F16_EST_HEADROOM (2^6): values up to 64x beyond it still
-// fit the fp16 range, anything larger saturates gracefully (the staged terms are clamped).  *est = float bits (plain store: one estimate per launch).
-__global__ __launch_bounds__(256) void bnbwd_estimate_kernel(const float* __restrict__ coef, int C, const unsigned* __restrict__ amax_in,
+// Rigorous upper bound of max |k1 (dz - m1 - xhat m2)| - the values of a BatchNorm backward - from the coefficient rows
+// [k1, m1, m2][C], the BatchNorm's mean / invstd rows, A = absmax of the incoming gradient and R = absmax of the raw tensor
+// (bnbwd_bound; the same value spk_bn_bwd_finalize(est_out=) gives without this launch).  *est = float bits (plain store).
+__global__ __launch_bounds__(256) void bnbwd_estimate_kernel(const float* __restrict__ coef, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int C,
+                                                             const unsigned* __restrict__ amax_in, const unsigned* __restrict__ raw_amax,
                                                              unsigned* __restrict__ est) {
     __shared__ float red[4];
-    const float A = __uint_as_float(*amax_in);
+    const float A = __uint_as_float(*amax_in), R = __uint_as_float(*raw_amax);
     float mx = 0.f;
     for (int c = threadIdx.x; c < C; c += 256)
-        mx = fmaxf(mx, SPK_F16_EST_HEADROOM * fabsf(coef[c]) * (A + fabsf(coef[C + c]) + 8.f * fabsf(coef[2 * C + c])));
+        mx = fmaxf(mx, bnbwd_bound(coef[c], coef[C + c], coef[2 * C + c], mean[c], invstd[c], A, R));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -525,9 +546,82 @@ extern "C" int spk_affine_estimate(const float* scale, const float* shift, int C
     return 0;
 }
 
-extern "C" int spk_bnbwd_estimate(const float* coef, int C, const unsigned* amax_in, unsigned* est, void* stream) {
-    SPK_REQUIRE(coef && amax_in && est && C > 0, "spk_bnbwd_estimate: bad arguments");
-    hipLaunchKernelGGL(bnbwd_estimate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, coef, C, amax_in, est);
+extern "C" int spk_bnbwd_estimate(const float* coef, const float* mean, const float* invstd, int C, const unsigned* amax_in,
+                                  const unsigned* raw_amax, unsigned* est, void* stream) {
+    SPK_REQUIRE(coef && mean && invstd && amax_in && raw_amax && est && C > 0, "spk_bnbwd_estimate: bad arguments");
+    hipLaunchKernelGGL(bnbwd_estimate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, coef, mean, invstd, C, amax_in, raw_amax, est);
     SPK_LAUNCH_CHECK("spk_bnbwd_estimate");
+    return 0;
+}
+
+// ---- f16x3 diagnostics: how a tensor sits in the two-term fp16 window of its scale slot ------------------------------------
+// counts[0] += values looked at, [1] += values that SATURATE (|v sigma| > 65504: must be 0, every slot is an absmax or a rigorous
+// bound), [2] += values whose low term is lost (0 < |lo| < 2^-14: fp16 subnormal, flushed by the matrix instruction - the
+// value is carried with 11 significand bits, an absolute error <= bound * 2^-29), [3] += values whose HIGH term is subnormal
+// (|v sigma| < 2^-14: carried as zero, absolute error <= bound * 2^-28).  v = x, or max(x*scale[c]+shift[c], 0) when scale is
+// given (what a convolution with the fused input BatchNorm+ReLU stages); pairs != 0: x is an f16 pair tensor (the window
+// is then read back from the stored terms; a stored high term of +-65504 counts as saturated).  Debug / test export: never
+// on the training path.
+__global__ __launch_bounds__(256) void f16_window_count_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, long long nquads, int C,
+                                                               const unsigned* __restrict__ slot, int pairs,
+                                                               unsigned long long* __restrict__ counts) {
+    const float sig = spk_sigma_from_amax_bits(*slot);
+    const int cmask = C - 1;
+    unsigned n = 0, sat = 0, lo_lost = 0, hi_sub = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
+        f32x4 v = *(const f32x4*)(x + i * 4);
+        float hi[4], lo[4];
+        if (pairs) {
+            const uint4 u = __builtin_bit_cast(uint4, v);
+            const f16x4 a = __builtin_bit_cast(f16x4, (uint2){u.x, u.y}), b = __builtin_bit_cast(f16x4, (uint2){u.z, u.w});
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = (float)a[k];
+                lo[k] = (float)b[k];
+                sat += fabsf(hi[k]) >= 65504.f;
+            }
+        } else {
+            if (scale) {
+                const int c = (int)((i * 4) & cmask);
+                v = v * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = v[k] * sig;
+                sat += fabsf(u) > 65504.f;
+                const float uc = __builtin_amdgcn_fmed3f(u, -65504.f, 65504.f);
+                const _Float16 a = (_Float16)uc;
+                hi[k] = (float)a;
+                lo[k] = (float)(_Float16)(uc - (float)a);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            n += 1;
+            lo_lost += lo[k] != 0.f && fabsf(lo[k]) < 6.103515625e-05f;
+            hi_sub += hi[k] != 0.f && fabsf(hi[k]) < 6.103515625e-05f;
+        }
+    }
+    unsigned vals[4] = {n, sat, lo_lost, hi_sub};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned v = vals[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + j, (unsigned long long)v);
+    }
+}
+
+extern "C" int spk_f16_window_count(const float* x, const float* scale, const float* shift, long long n, int C,
+                                    const unsigned* slot, int pairs, unsigned long long* counts, void* stream) {
+    SPK_REQUIRE(x && slot && counts && n > 0 && n % 4 == 0, "spk_f16_window_count: bad arguments (n must be a multiple of 4)");
+    SPK_REQUIRE((scale == nullptr) == (shift == nullptr), "spk_f16_window_count: scale / shift come in pairs");
+    SPK_REQUIRE(!scale || (bn_c_ok(C) && !pairs), "spk_f16_window_count: the affine form needs a power-of-two C and an fp32 tensor");
+    hipLaunchKernelGGL(f16_window_count_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, n / 4,
+                       scale ? C : 4, slot, pairs, counts);
+    SPK_LAUNCH_CHECK("spk_f16_window_count");
     return 0;
 }

@@ -89,7 +89,10 @@ struct ConvArgs {
 #ifndef PIPE_VPM
 #define PIPE_VPM 6      // VALU instructions scheduled behind every MFMA of a pipelined tap (2 / 4 / 6 / 8 measured: 57.08 / 57.29 / 56.94 / 56.9 ms per step)
 #endif
-template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false>
+// PRE (PIPE only): the input is an f16 pair tensor (spk_common.h): staging item = one 16-byte load + two 8-byte LDS writes, no
+// conversion - the data gradients whose BatchNorm backward ran as a separate pass (spk_bn_bwd_apply with pair output).
+// The non-pipelined f16x3 kernels take pair tensors through the run-time flag SPK_IN_PRESPLIT.
+template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false>
 static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
     constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
@@ -166,15 +169,18 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int cout32 = a.Cout >> 5;
     const int quad = tid & (TPP - 1);   // this thread's float4 of channels within a staged pixel
     const int prow = tid / TPP;         // and its pixel slot within a staging pass
+    auto store_pair = [&](float* plane, int p, uint2 t0, uint2 t1) {      // f16x3: the two terms of one float4 of channels
+        uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;      // [term][CK ch]: CK*2 bytes per term
+        dst[0] = t0;
+        dst[CK / 4] = t1;
+    };
     auto store_px = [&](float* plane, int p, f32x4 w) {
         if constexpr (SPLIT == 0) {
             *(f32x4*)(plane + p * (LP4 * 4) + quad * 4) = w;
         } else if constexpr (SPLIT == 3) {
             uint2 t0, t1;
             split2h(w, sig, t0, t1);
-            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][CK ch]: CK*2 bytes per term
-            dst[0] = t0;
-            dst[CK / 4] = t1;
+            store_pair(plane, p, t0, t1);
         } else {
             uint2 t0, t1, t2;
             split3(w, t0, t1, t2);
@@ -244,9 +250,17 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         f32x4 w = k1 * (dz - m1 - ((rw[u] - mu) * is) * m2);
                         if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (p < halo_pix) {
-                            store_px(ldsp, p, w);
+                            f32x4 side = w;
+                            if constexpr (SPLIT == 3) {
+                                uint2 t0, t1;
+                                split2h(w, sig, t0, t1);
+                                store_pair(ldsp, p, t0, t1);
+                                // the gradient wrt the raw conv output leaves as an f16 pair tensor: the terms just formed, for free
+                                if (flags & SPK_SIDE_PRESPLIT) side = spk_pair_pack(t0, t1);
+                            } else
+                                store_px(ldsp, p, w);
                             if (owner && core[u]) {
-                                *(f32x4*)(img_draw + off[u]) = w;
+                                *(f32x4*)(img_draw + off[u]) = side;
                                 if (a.side_dz) *(f32x4*)(img_dz + off[u]) = dz;
                                 side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                             }
@@ -287,6 +301,14 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             w[3] = fmaxf(w[3], 0.f);
                         }
                         if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if constexpr (SPLIT == 3) {
+                            if (flags & SPK_IN_PRESPLIT) {           // f16 pair tensor: the 16 bytes ARE the two terms
+                                uint2 t0, t1;
+                                spk_pair_unpack(w, t0, t1);
+                                if (p < halo_pix) store_pair(ldsp, p, t0, t1);
+                                continue;
+                            }
+                        }
                         if (p < halo_pix) store_px(ldsp, p, w);
                     }
                 }
@@ -513,6 +535,12 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         sd_off = pof[u % PIPE_D];
                         const float mx = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
                         side_mx = sd_go ? fmaxf(side_mx, mx) : side_mx;
+                    } else if constexpr (PRE) {
+                        // f16 pair tensor: select zero bits outside the image, write the two terms as they are
+                        const uint4 b = __builtin_bit_cast(uint4, pre[u % PIPE_D]);
+                        const uint2 t0 = {ok ? b.x : 0u, ok ? b.y : 0u}, t1 = {ok ? b.z : 0u, ok ? b.w : 0u};
+                        store_pair(real ? nxt : dump, real ? p : 0, t0, t1);
+                        return;
                     } else {
                         w = pre[u % PIPE_D] * scn + shn;
 #pragma unroll
@@ -798,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // the in-wave pipelined form (f16x3 operands; conv_pipe.hip)
 // BITS (fused BatchNorm backward only): the ReLU mask comes as sign bits (in_mask); otherwise it is recomputed from the raw
 // conv output (in_act is not supported here: such launches stay on conv_mfma_kernel)
-template <int MT, int NT, bool BNBWD, bool BITS = false>
+template <int MT, int NT, bool BNBWD, bool BITS = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(ConvArgs a) {        // two blocks per CU: 256 registers per lane
-    conv_body<MT, NT, BNBWD, 3, true, BITS>(a);
+    conv_body<MT, NT, BNBWD, 3, true, BITS, PRE>(a);
 }

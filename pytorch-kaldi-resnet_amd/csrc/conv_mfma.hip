@@ -80,6 +80,13 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
                 "spk_conv_mfma: IN_BNBWD is defined for stride-1 data gradients (input and output grids coincide)");
     SPK_REQUIRE(!(flags & SPK_EPI_BNBWD) || ((flags & SPK_EPI_STATS) && bn_raw && bn4),
                 "spk_conv_mfma: EPI_BNBWD needs EPI_STATS, bn_raw and bn4");
+    // f16x3: the operand scale ALWAYS comes from a slot (an absmax written by the producer, or a rigorous bound): a static scale
+    // would clamp |v| > 1023 and flush small gradients silently
+    SPK_REQUIRE(split != 3 || in_amax, "spk_conv_mfma: the f16x3 operand mode needs in_amax (slot with the float bits of the staged tensor's absmax or of an upper bound)");
+    SPK_REQUIRE(!(flags & SPK_IN_PRESPLIT) || (split == 3 && !(flags & (SPK_IN_AFFINE_RELU | SPK_IN_BNBWD | SPK_CONV_WS))),
+                "spk_conv_mfma: IN_PRESPLIT (f16 pair input) needs the f16x3 mode, a plain input, and not the wave-specialised kernel");
+    SPK_REQUIRE(!(flags & SPK_SIDE_PRESPLIT) || ((flags & SPK_IN_BNBWD) && split == 3 && !(flags & (SPK_CONV_WS | SPK_CONV_PIPE))),
+                "spk_conv_mfma: SIDE_PRESPLIT (f16 pair side output) exists for the fused BatchNorm-backward form of conv_mfma_kernel in the f16x3 mode");
     ConvArgs a;
     a.in = in; a.wpk = wpk; a.out = out; a.in_scale = in_scale; a.in_shift = in_shift;
     a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_add = epi_add; a.stats = stats;

@@ -14,7 +14,9 @@ static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
             spk_set_error("spk_conv_mfma: no pipelined fused-BatchNorm-backward kernel for MT=%d NT=%d", MT, NT);
             return -1;
         }
-    } else
+    } else if (a.flags & SPK_IN_PRESPLIT)        // f16 pair input: staging by plain copy
+        hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    else
         hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_mfma(pipe)");
     return 0;

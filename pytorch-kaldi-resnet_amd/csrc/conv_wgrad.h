@@ -23,7 +23,8 @@ struct WgradArgs {
     int halo_h, halo_w;
     unsigned halo_w_magic, tw_magic;   // ceil(2^32 / d) for exact small-range division
     int flags;
-    const unsigned* dy_amax;   // f16x3 (split 3): float bits of absmax(dy) -> dY operand scale 2^(8 - exponent); NULL: scale 1
-    const unsigned* x_amax;    //   same for the X operand (absmax of the staged values or an upper estimate); NULL: static 2^6
+    const unsigned* dy_amax;   // f16x3 (split 3): float bits of absmax(dy), or of an upper bound -> the dY operand scale, the power
+                               //   of two that takes that value into [2^14, 2^15) (spk_sigma_from_amax_bits); required
+    const unsigned* x_amax;    //   same for the X operand (absmax of the STAGED values - after a fused BatchNorm+ReLU - or a bound)
 };
 

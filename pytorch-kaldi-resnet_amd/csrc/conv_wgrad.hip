@@ -303,10 +303,15 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     a.dy_amax = dy_amax; a.x_amax = x_amax;
     SPK_REQUIRE(split == 0 || split == 3 || ((split == 6 || split == 9) && ksize == 3),
                 "spk_conv_wgrad: split=%d (0; 3 = f16x3, any kernel size; 6 / 9 = bf16 terms, 3x3 only)", split);
+    // f16x3: both operand scales ALWAYS come from slots (a NULL dy_amax meant scale 1 - typical gradients of 1e-5..1e-8
+    // then became fp16 subnormals, flushed by the matrix instruction: dw silently ~0)
+    SPK_REQUIRE(split != 3 || (dy_amax && x_amax), "spk_conv_wgrad: the f16x3 operand mode needs dy_amax and x_amax (slots with the float bits of the operands' absmax or of upper bounds)");
+    SPK_REQUIRE(!(flags & SPK_DY_PRESPLIT) || (split == 3 && !(flags & (SPK_CONV_PIPE | SPK_CONV_WS))),
+                "spk_conv_wgrad: DY_PRESPLIT (dy as an f16 pair tensor) needs the f16x3 mode (not the opt-in pipelined / wave-specialised forms)");
     if (flags & SPK_WGRAD_GROUPS) {       // f16x3: bits 12-13 of flags = log2 of the input-channel groups per block
         SPK_REQUIRE(split == 3, "spk_conv_wgrad: the grouped kernels exist in the f16x3 mode");
         const int cg = 1 << ((flags >> 12) & 3);
-        a.flags = flags & SPK_IN_AFFINE_RELU;
+        a.flags = flags & (SPK_IN_AFFINE_RELU | SPK_DY_PRESPLIT);
         if (ksize == 3) {                 // 3x3: two groups = the 2 x 2 wave layout
             SPK_REQUIRE(cg == 2 && WN == 2, "spk_conv_wgrad: the 3x3 grouped kernel has 2 input-channel groups and WN = 2");
             return spk_launch_wgrad_wm(a, (hipStream_t)stream);

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_1x1_kernel(WgradArgs a) {
     const int flags = a.flags;
     const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
     const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
+    const bool dy_pairs = (a.flags & SPK_DY_PRESPLIT) != 0;    // dY is an f16 pair tensor: staged by plain copy
 
     f32x16 acc[CG];
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_1x1_kernel(WgradArgs a) {
             if (p < npix_pad) {
                 uint2* dst = (uint2*)(dys + p * PD + (cq >> 3) * 192) + (cq & 7);
                 uint2 t0, t1;
-                split2h(w, sig_d, t0, t1);
+                spk_terms(w, sig_d, dy_pairs, t0, t1);
                 dst[0] = t0;
                 dst[8] = t1;
             }

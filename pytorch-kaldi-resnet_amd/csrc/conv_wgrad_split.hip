@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
                 uint2* dst = (uint2*)(dys + p * PD + (cq >> 3) * 192) + (cq & 7);
                 if constexpr (SPLIT == 3) {
                     uint2 t0, t1;
-                    split2h(w, sig_d, t0, t1);
+                    spk_terms(w, sig_d, (flags & SPK_DY_PRESPLIT) != 0, t0, t1);     // f16 pair tensor: plain copy
                     dst[0] = t0;
                     dst[8] = t1;
                 } else {

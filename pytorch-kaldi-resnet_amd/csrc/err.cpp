@@ -13,4 +13,4 @@ void spk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* spk_last_error(void) { return g_err; }
-extern "C" int spk_version(void) { return 100; }
+extern "C" int spk_version(void) { return 300; }

@@ -36,7 +36,12 @@ enum {
     SPK_CONV_WS = 128,        // launch the producer/consumer (wave-specialised, persistent) kernel: bf16-split 3x3 only
                               //   (bits 8-9 of the flags word then carry log2 of its consumer-wave channel groups)
     SPK_CONV_PIPE = 1024,     // launch the in-wave pipelined kernel (conv_kernel.h, PIPE): f16x3, 3x3, plain input
-    SPK_WGRAD_GROUPS = 2048   // spk_conv_wgrad, 1x1, f16x3: conv_wgrad_1x1_kernel with 1 << (flags bits 12-13) channel groups
+    SPK_WGRAD_GROUPS = 2048,  // spk_conv_wgrad, 1x1, f16x3: conv_wgrad_1x1_kernel with 1 << (flags bits 12-13) channel groups
+    // f16x3 "pair" tensors (see below): a gradient tensor written ONCE in the two-term fp16 form by its producer and staged by
+    // plain copy in every matrix-core kernel that consumes it
+    SPK_IN_PRESPLIT = 1 << 14,    // spk_conv_mfma: `in` holds f16 pairs scaled by the sigma of in_amax (no input transform)
+    SPK_SIDE_PRESPLIT = 1 << 15,  // spk_conv_mfma + IN_BNBWD: side_draw is written as f16 pairs (scale: the sigma of in_amax)
+    SPK_DY_PRESPLIT = 1 << 16     // spk_conv_wgrad: `dy` holds f16 pairs scaled by the sigma of dy_amax
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -82,13 +87,32 @@ static __device__ __forceinline__ void split2h(f32x4 w, float sigma, uint2& t0, 
     t0 = __builtin_bit_cast(uint2, a);
     t1 = __builtin_bit_cast(uint2, b);
 }
+// ---- f16 pair tensors.  Same shape and addressing as the fp32 NHWC tensor they stand for; every aligned group of four
+// floats (16 bytes) is replaced by [4 x fp16 high term][4 x fp16 low term] of value * sigma, sigma = the power of two that
+// spk_sigma_from_amax_bits derives from the tensor's scale slot (a rigorous upper bound of its absmax, known BEFORE the
+// producer runs).  The producer (spk_bn_bwd_apply, or the side output of a fused BatchNorm-backward data gradient) converts
+// each value exactly once; the data gradient and the weight gradient that consume it stage 16-byte groups by plain copy
+// (two 8-byte LDS writes, no conversion), where they used to convert the same value Cout/64 + Cin/64 times.
+static __device__ __forceinline__ f32x4 spk_pair_pack(uint2 t0, uint2 t1) {
+    return __builtin_bit_cast(f32x4, (uint4){t0.x, t0.y, t1.x, t1.y});
+}
+static __device__ __forceinline__ void spk_pair_unpack(f32x4 v, uint2& t0, uint2& t1) {
+    const uint4 u = __builtin_bit_cast(uint4, v);
+    t0 = (uint2){u.x, u.y};
+    t1 = (uint2){u.z, u.w};
+}
+// the two fp16 terms of one float4 of an operand: converted here, or - `pairs`, wave-uniform - taken as stored (f16 pair tensor)
+static __device__ __forceinline__ void spk_terms(f32x4 w, float sigma, bool pairs, uint2& t0, uint2& t1) {
+    if (pairs) spk_pair_unpack(w, t0, t1);
+    else split2h(w, sigma, t0, t1);
+}
 // power-of-two scale from the bits of a tensor's absmax (or of an upper bound of it): amax * sigma in [2^14, 2^15), just
 // under the fp16 maximum (65504): every value >= amax * 2^-18 keeps both terms normal (22 significant bits); smaller ones
 // lose the low term (fp16 subnormals do not survive the matrix instruction) and are carried with 11 bits - an absolute
 // error <= amax * 2^-30 per element, visible only when one element outweighs the rest of its tensor by > 10^5
 // (tests/test_kernels_gpu.py::test_f16x3_precision_floor_below_the_scale_window; the bf16 modes have no such floor).  Heuristic (non-rigorous) estimates carry their
-// own headroom factor (SPK_F16_EST_HEADROOM) so that the staged values still fit.
-#define SPK_F16_EST_HEADROOM 64.0f
+// own headroom factor - none is left: every scale now comes from a true absmax or from a rigorous bound
+// (bn.hip: bn_finalize_kernel for relu(raw*scale+shift), bn_bwd_finalize_kernel for the BatchNorm-backward values).
 static __device__ __forceinline__ float spk_sigma_from_amax_bits(unsigned bits) {
     const int e = (int)((bits >> 23) & 0xffu);            // biased exponent; amax = m * 2^(e - 127), m in [1, 2)
     if (e == 0 || e == 255) return 1.f;                   // zero / subnormal / inf / nan: no scaling

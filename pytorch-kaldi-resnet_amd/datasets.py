@@ -5,7 +5,7 @@ EmbeddingDataset :148-193), rewritten here: same class-balancing rule, same rand
 layout (freq-major, time innermost) - and runnable on numpy >= 1.24 (the reference's np.int is gone).
 """
 import numpy as np
-from torch.utils.data import Dataset
+from torch.utils.data import Dataset, Sampler
 
 from . import kaldi_io
 
@@ -23,6 +23,50 @@ def _crop(full, seq_len):
     assert len(full) >= seq_len
     pin = np.random.randint(0, len(full) - seq_len + 1)
     return np.ascontiguousarray(full[pin:pin + seq_len, :].T)
+
+
+def chunk_length_schedule(lo, hi, quantum, nbatches, seed, epoch):
+    """One chunk length per batch for variable-length training (the reference draws lengths in [min, max] per sample,
+    scripts/datasets.py:40-43, which default collation cannot batch; SURVEY.md section 5: one T per batch).  Lengths are
+    lo, lo + quantum, ... <= hi; the draw depends on (seed, epoch) only, so every rank sees the same length for batch i."""
+    lo, hi, quantum = int(lo), int(hi), max(1, int(quantum))
+    assert 0 < lo <= hi
+    choices = np.arange(lo, hi + 1, quantum)
+    g = np.random.RandomState((int(seed) * 1000003 + int(epoch) * 7919 + 12345) % (2 ** 31 - 1))
+    return choices[g.randint(0, len(choices), size=int(nbatches))]
+
+
+class ChunkBatchSampler(Sampler):
+    """Batch sampler for variable-length training: wraps an index sampler (RandomSampler / DistributedSampler) and yields
+    batches of (index, T) pairs whose T comes from chunk_length_schedule - the length travels WITH the index, so DataLoader
+    worker processes need no shared state (Dataset.set_chunk_size in the parent would not reach them)."""
+
+    def __init__(self, sampler, batch_size, lo, hi, quantum=8, seed=0, drop_last=False):
+        self.sampler, self.batch_size, self.drop_last = sampler, int(batch_size), drop_last
+        self.lo, self.hi, self.quantum, self.seed, self.epoch = lo, hi, quantum, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        if hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(epoch)
+
+    def __len__(self):
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        idx = list(self.sampler)
+        lens = chunk_length_schedule(self.lo, self.hi, self.quantum, len(self), self.seed, self.epoch)
+        for b in range(len(self)):
+            sel = idx[b * self.batch_size:(b + 1) * self.batch_size]
+            yield [(int(i), int(lens[b])) for i in sel]
+
+
+def _index_and_len(index, default_len):
+    """Dataset index: a plain int (chunk length from the dataset), or an (index, T) pair from ChunkBatchSampler"""
+    if isinstance(index, (tuple, list)):
+        return int(index[0]), int(index[1])
+    return index, default_len
 
 
 class SequenceDataset(Dataset):
@@ -58,8 +102,9 @@ class SequenceDataset(Dataset):
         self.seq_len = seq_len
 
     def __getitem__(self, index):
+        index, T = _index_and_len(index, None)
         full = kaldi_io.read_mat(self.rxfiles[index])
-        return _crop(full, int(self.seq_len[index])), np.array(self.labels[index])
+        return _crop(full, int(self.seq_len[index]) if T is None else T), np.array(self.labels[index])
 
 
 class SequenceDataset2(Dataset):
@@ -87,10 +132,11 @@ class SequenceDataset2(Dataset):
         self.seq_len = seq_len
 
     def __getitem__(self, index):
+        index, T = _index_and_len(index, self.seq_len)
         spk = self.labels[index % self.num_spk]
         files = self.rxfiles[spk]
         full = kaldi_io.read_mat(files[np.random.randint(0, len(files))])
-        return _crop(full, self.seq_len), np.array(spk)
+        return _crop(full, T), np.array(spk)
 
 
 class EmbeddingDataset(Dataset):

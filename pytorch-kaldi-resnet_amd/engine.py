@@ -114,7 +114,9 @@ class Engine:
         self._packed_for_bwd = False
         self._pack_tables = {}
         self._amax_pool = None
-        self._amax_fwd = None
+        self._amax_fwd = None          # slots of the TRAINING forward: they live on in the saved records until its backward
+        self._amax_eval = None         # slots of eval-mode / no-grad forwards (never referenced by a backward)
+        self._fwd_gen = 0              # generation of the training table: a backward refuses records of an older forward
         # weight gradients (compute-bound, off the critical path) run on a side stream so that they overlap the
         # HBM-bound BatchNorm-backward passes of the main dgrad chain
         self.wgrad_stream = None
@@ -128,9 +130,28 @@ class Engine:
         import os
         self.use_sign_masks = os.environ.get("SPK_SIGN_MASKS", "1") == "1"
         self.fuse_apply_min_c = int(os.environ.get("SPK_FUSE_APPLY_MINC", "0"))   # experiment knob: skip the fusion below C channels
-        self.fuse_apply_max_c = int(os.environ.get("SPK_FUSE_APPLY_MAXC", "1000000"))   # ... and above
+        # ... and above.  f16x3 default: the fusion only on the 32-channel layer, which is HBM-bound (the fusion saves one tensor
+        # read there); from 64 channels on the BatchNorm backward runs as its own pass that writes the gradient ONCE as an f16
+        # pair tensor, and the data gradient (in-wave pipelined kernel) and the weight gradient stage it by plain copy
+        # (None = by operand mode: 32 in the f16x3 mode with pair tensors, no limit otherwise; SPK_FUSE_APPLY_MAXC overrides)
+        self._fuse_apply_max_c = int(os.environ["SPK_FUSE_APPLY_MAXC"]) if "SPK_FUSE_APPLY_MAXC" in os.environ else None
+        # gradients wrt raw conv outputs travel as f16 pair tensors (include/spkhip.h) in the f16x3 mode
+        self.pair_draw = os.environ.get("SPK_PAIR_DRAW", "1") == "1"
+        # diagnostics (tests / bench, never the timed path): when a [4] int64 device tensor, every tensor that an f16x3
+        # matrix-core kernel stages is also run through spk_f16_window_count under the scale slot its consumer uses
+        self.window_counts = None
 
     # ---- helpers ---------------------------------------------------------------------------------------
+    @property
+    def fuse_apply_max_c(self):
+        if self._fuse_apply_max_c is not None:
+            return self._fuse_apply_max_c
+        return 32 if (self.pair_draw and ops.split_for(3, True) == 3) else 1000000
+
+    @fuse_apply_max_c.setter
+    def fuse_apply_max_c(self, v):
+        self._fuse_apply_max_c = v
+
     def _all_convs(self):
         for b in self.blocks:
             for c in b.convs:
@@ -164,15 +185,25 @@ class Engine:
         return x.contiguous()
 
     # ---- inference trunk (eval-mode BN folded into conv epilogues) -----------------------------------------
-    def _fwd_pool(self, device):
-        """absmax slot table of the forward pass (f16x3 operand mode): reset at the start of every forward; the slots of
-        the convolution inputs live on in the saved records for the weight gradients."""
+    def _fwd_pool(self, device, train=False):
+        """absmax slot table of a forward pass (f16x3 operand mode), reset at its start.  The training forward has a table of
+        its own: its slots (convolution inputs, raw conv outputs) live on in the saved records for the backward pass, so an
+        eval-mode or no-grad forward between forward_train and backward must not touch them (it takes the other table), and
+        a SECOND training forward before the backward invalidates the records (generation check in Engine.backward)."""
         if ops.split_for(3) != 3 and ops.split_for(3, True) != 3:
             return None
-        if self._amax_fwd is None:
-            self._amax_fwd = ops.AmaxPool(device)
-        self._amax_fwd.reset()
-        return self._amax_fwd
+        name = "_amax_fwd" if train else "_amax_eval"
+        if getattr(self, name) is None:
+            setattr(self, name, ops.AmaxPool(device))
+        pool = getattr(self, name)
+        pool.reset()
+        if train:
+            self._fwd_gen += 1
+        return pool
+
+    def _count(self, x, slot, affine=None, pairs=False):
+        if self.window_counts is not None and slot is not None:
+            ops.f16_window_count(x, slot, self.window_counts, affine=affine, pairs=pairs)
 
     def trunk_eval(self, x):
         self._repack(False)
@@ -268,7 +299,8 @@ class Engine:
     # ---- training forward -----------------------------------------------------------------------------------
     def _trunk_train(self, x, save):
         saved = {"x": x, "blocks": []}
-        pool = self._fwd_pool(x.device)
+        pool = self._fwd_pool(x.device, train=save)
+        saved["amax_gen"] = self._fwd_gen
         take = (lambda: pool.take()) if pool is not None else (lambda: None)
         f16 = ops.split_for(3) == 3
         raw0, st = ops.stem_fwd(x, self.stem_conv.h.weight.data, stats=True)
@@ -282,12 +314,15 @@ class Engine:
         for b in self.blocks:
             # in_amax[i]: slot with the absmax (or its upper estimate) of the values conv_i STAGES - the block input itself,
             # or relu(bn(raw_{i-1})) recomputed in the staging - shared by the forward conv and its weight gradient
-            rec = {"x": a, "xmask": amask, "in_amax": []}
+            rec = {"x": a, "xmask": amask, "in_amax": [], "raw_amax": []}
             raws = []
             h, aff, h_amax = a, None, a_amax           # h_amax: slot describing the values the next conv stages from h
             for c, bn in zip(b.convs, b.bns):
                 rec["in_amax"].append(h_amax)
                 raw_amax = take()
+                rec["raw_amax"].append(raw_amax)       # absmax(raw): bounds |xhat| in the BatchNorm backward's operand scale
+                if ops.split_for(c.k) == 3:
+                    self._count(h, h_amax, affine=aff)
                 raw, st = ops.conv_fwd(h, c.wpk, c.cout, c.k, c.stride, in_affine=aff, stats=True,
                                        in_amax=h_amax if ops.split_for(c.k) == 3 else None, out_amax=raw_amax)
                 # the next conv stages relu(bn(raw)): its operand-scale bound comes out of the BatchNorm finalize
@@ -344,10 +379,10 @@ class Engine:
             return logits
 
     # ---- side-stream weight gradients ----------------------------------------------------------------------------
-    def _wgrad(self, x, dy, dw, k, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None):
+    def _wgrad(self, x, dy, dw, k, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None, dy_presplit=False):
         if not self.use_side_stream:
             return ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax,
-                                  x_amax=x_amax)
+                                  x_amax=x_amax, dy_presplit=dy_presplit)
         if self.wgrad_stream is None:
             self.wgrad_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -358,7 +393,8 @@ class Engine:
                 t.record_stream(side)               # keep the allocator from recycling them under the side kernel
         # (inside a graph capture the private pool keeps every tensor of the captured region alive)
         with torch.cuda.stream(side):
-            ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax, x_amax=x_amax)
+            ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax, x_amax=x_amax,
+                           dy_presplit=dy_presplit)
 
     def _join_wgrad(self):
         if self.use_side_stream and self.wgrad_stream is not None:
@@ -371,6 +407,9 @@ class Engine:
         gradient of each ResNet stage has been enqueued (hook for overlapping the gradient all-reduce)."""
         m = self.m
         acc = not m.attach_grads()
+        if self._amax_fwd is not None and saved.get("amax_gen") != self._fwd_gen:
+            raise RuntimeError("backward of a training forward whose operand-scale slots were reused by a later training forward "
+                               "(f16x3 mode keeps one slot table per engine: run backward before the next forward_train)")
         with torch.no_grad():
             demb = self._head_bwd(saved["emb"], saved["head"], dlogits, acc)
             dpooled = ops.linear_bwd(saved["pooled"], m.fc1.weight.data, demb, m.fc1.weight.grad, m.fc1.bias.grad,
@@ -448,12 +487,16 @@ class Engine:
                     if rec.get("xmask") is not None:
                         bnb = bnb + (rec["xmask"],)                     # sign bits of x instead of x itself
             res_amax, draw_amax = take(), take()
+            # f16x3: the gradient wrt the raw conv output (draw) travels as an f16 PAIR tensor - written once in the two-term
+            # form under a rigorous bound known before it is computed, staged by plain copy in its data and weight gradients
+            pairs = f16 and self.pair_draw
+            raw_amax = rec["raw_amax"][i] if f16 else None
             if self.fuse_bn_apply and c.stride == 1 and self.fuse_apply_min_c <= c.cout <= self.fuse_apply_max_c:
                 if g_part is None:
                     g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
                 est = take() if f16 else None
                 coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,
-                                       bn.h.bias.grad, acc, amax_in=g_amax, est_out=est)
+                                       bn.h.bias.grad, acc, amax_in=g_amax, raw_amax=raw_amax, est_out=est)
                 draw = torch.empty_like(raw)
                 # the shortcut gradient dz = dout*[out > 0]: with an identity shortcut and sign masks it is never stored - the
                 # first conv's data-gradient epilogue re-forms it from dout and the mask bits
@@ -464,14 +507,20 @@ class Engine:
                     inb = inb + (rec["mask"],)                          # sign bits of the block output instead of it
                 if add_dz and lazy_dz:
                     res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
-                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax)
+                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax,
+                                         side_presplit=pairs)
                 else:
                     res = ops.conv_dgrad(g, c.wpk_t, c.cin, c.k, 1, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax)
+                                         in_bnbwd=inb, side=(draw, dzb), in_amax=est, out_amax=res_amax, side_amax=draw_amax,
+                                         side_presplit=pairs)
                 if last:
                     dz = dzb
+                draw_slot = est if pairs else draw_amax
+                self._count(draw, draw_slot, pairs=pairs)
             else:
                 lazy_dz = False
+                est = take() if pairs else None
+                pair = (g_amax, raw_amax, est) if pairs else None
                 if last:
                     # separate BatchNorm-backward pass (then a plain, pipelined data gradient).  With sign masks it reads the
                     # bits instead of the block output, and with an identity shortcut dz is not stored: the first conv's
@@ -480,21 +529,24 @@ class Engine:
                     lazy_dz = b.ds is None and bits is not None and n > 1
                     draw = ops.bn_backward(g, raw, bits if bits is not None else out, bn.t4, bn.h.weight.data, bn.h.weight.grad,
                                            bn.h.bias.grad, MASK_BITS if bits is not None else MASK_ACT,
-                                           dz_out=None if lazy_dz else g, accumulate=acc, partial=g_part, amax_out=draw_amax)
+                                           dz_out=None if lazy_dz else g, accumulate=acc, partial=g_part, amax_out=draw_amax,
+                                           pair=pair)
                     dz = None if lazy_dz else g                         # (dout now holds dz)
                 else:
                     draw = ops.bn_backward(g, raw, None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_RAW,
-                                           draw_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax)
+                                           draw_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax, pair=pair)
+                draw_slot = est if pairs else draw_amax
+                self._count(draw, draw_slot, pairs=pairs)
                 if add_dz and dz is None and rec.get("mask") is not None:
                     res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
-                                         in_amax=draw_amax if f16 else None, out_amax=res_amax)
+                                         in_amax=draw_slot if f16 else None, out_amax=res_amax, in_presplit=pairs)
                 else:
                     res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dz if add_dz else None, bn_bwd=bnb,
-                                         in_amax=draw_amax if f16 else None, out_amax=res_amax)
+                                         in_amax=draw_slot if f16 else None, out_amax=res_amax, in_presplit=pairs)
             g, g_part = res if bnb is not None else (res, None)
             g_amax = res_amax
             self._wgrad(inp, draw, c.h.weight.grad, c.k, c.stride, in_affine=in_aff, accumulate=acc,
-                        dy_amax=draw_amax if f16 else None, x_amax=rec["in_amax"][i] if f16 else None)
+                        dy_amax=draw_slot if f16 else None, x_amax=rec["in_amax"][i] if f16 else None, dy_presplit=pairs)
         dx, part, dx_amax = g, g_part, g_amax
         if b.ds is not None:
             cd, bnd = b.ds
@@ -502,6 +554,7 @@ class Engine:
             drawd_amax = take() if f16d else None
             drawd = ops.bn_backward(dz, rec["rawd"], None, bnd.t4, bnd.h.weight.data, bnd.h.weight.grad, bnd.h.bias.grad,
                                     MASK_NONE, draw_out=dz, accumulate=acc, amax_out=drawd_amax)
+            self._count(drawd, drawd_amax)
             self._wgrad(x, drawd, cd.h.weight.grad, 1, cd.stride, accumulate=acc, dy_amax=drawd_amax,
                         x_amax=rec["in_amax"][0] if f16d else None)
             # the 1x1 gradient lands on top of the 3x3 one: the same slot ends up >= the absmax of the sum's final values
@@ -632,3 +685,43 @@ class GraphedTrainStep:
         self.eng.dirty, self.eng._packed_for_bwd = False, True
         self.eng.m.attach_grads()
         return self.loss, self.logits, self.rank
+
+
+class GraphedStepCache:
+    """Variable-length training (BASELINE configs[3]; reference scripts/datasets.py:40-43,53-57: chunk lengths drawn in
+    [min, max], here ONE length per batch, identical on every rank): a GraphedTrainStep per (batch, frames), captured on
+    first use, all sharing ONE memory pool - steps of different lengths are never replayed concurrently, so the cache costs
+    the activation memory of the longest length it has seen, not the sum - and at most `max_graphs` of them (least recently
+    used dropped first).  Host cost per step after the first visit of a length: the replay launches, < 1 ms."""
+
+    def __init__(self, engine, segmented=False, max_graphs=64, warmup=2):
+        self.eng, self.segmented, self.max_graphs, self.warmup = engine, segmented, max_graphs, warmup
+        self.steps = {}            # (batch, frames) -> GraphedTrainStep, in least-recently-used order
+        self._pool_owner = None    # keeps the shared pool alive even after its first graph was dropped
+        self.captures = 0
+
+    def get(self, batch, frames):
+        key = (int(batch), int(frames))
+        st = self.steps.pop(key, None)
+        if st is None:
+            pool = self._pool_owner.pool() if self._pool_owner is not None else None
+            st = GraphedTrainStep(self.eng, key[0], key[1], warmup=self.warmup, segmented=self.segmented, pool=pool)
+            if self._pool_owner is None:
+                self._pool_owner = st
+            self.captures += 1
+            while len(self.steps) >= self.max_graphs:
+                old = next(iter(self.steps))
+                if self.steps[old] is self._pool_owner:      # never drop the owner of the pool: re-queue it
+                    self.steps[old] = self.steps.pop(old)
+                    if len(self.steps) == 1:
+                        break
+                    continue
+                del self.steps[old]
+        self.steps[key] = st
+        return st
+
+    def __call__(self, x, y, on_stage_done=None):
+        return self.get(x.shape[0], x.shape[2])(x, y, on_stage_done)
+
+    def __len__(self):
+        return len(self.steps)

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SPK_LIB", os.path.join(_HERE, "libspkhip.so"))   # SP
 IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD, IN_BNBWD, CONV_WS = 1, 2, 4, 8, 16, 32, 64, 128
 CONV_PIPE = 1024
 WGRAD_GROUPS = 2048        # spk_conv_wgrad flags: 1x1 f16x3 kernel with 1 << (bits 12-13) input-channel groups per block
+IN_PRESPLIT, SIDE_PRESPLIT, DY_PRESPLIT = 1 << 14, 1 << 15, 1 << 16     # f16 pair tensors (include/spkhip.h)
 MASK_NONE, MASK_ACT, MASK_RAW, MASK_BITS = 0, 1, 2, 3
 
 _P = ctypes.c_void_p
@@ -39,10 +40,11 @@ _SIGS = {
     "spk_bn_eval_coeffs": [_P] * 6 + [_I, _F, _P],
     "spk_bn_apply": [_P] * 8 + [_L, _I, _I, _P, _P],
     "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P],
-    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P, _P, _P],
-    "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P, _P],
+    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P, _P, _P, _P, _P],
+    "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P, _P, _P],
     "spk_absmax": [_P, _P, _L, _P],
-    "spk_bnbwd_estimate": [_P, _I, _P, _P, _P],
+    "spk_bnbwd_estimate": [_P, _P, _P, _I, _P, _P, _P, _P],
+    "spk_f16_window_count": [_P, _P, _P, _L, _I, _P, _I, _P, _P],
     "spk_affine_estimate": [_P, _P, _I, _P, _P, _P],
     "spk_stats_pool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -105,8 +105,11 @@ class NativeTrainLoader:
     """Iterable over (features [B,F,T] pinned, labels [B] int64) batches of one epoch for this rank."""
 
     def __init__(self, scp_file, utt2spkid_file, chunk_size, batch_size, rank=0, world=1, seed=0, threads=4,
-                 drop_last=False, prefetch=2, device=None):
-        """device=None: batches are fresh pageable host tensors (the caller copies them; a copy from pageable memory is
+                 drop_last=False, prefetch=2, device=None, chunk_range=None):
+        """chunk_range=(lo, hi, quantum): variable-length training - one chunk length per batch from
+        datasets.chunk_length_schedule (seeded by (seed, epoch) only: the same length on every rank); chunk_size is then
+        ignored and the pinned ring is sized for hi.
+        device=None: batches are fresh pageable host tensors (the caller copies them; a copy from pageable memory is
         staged by the runtime before .cuda() returns, so nothing can overwrite it early).
         device=cuda:N: the loader owns a ring of PINNED staging buffers and the host->device copy: it issues the copy on
         its own copy stream (overlapping the previous step's kernels), records an event per ring slot, and the reader
@@ -133,7 +136,8 @@ class NativeTrainLoader:
         self.table = ArkTable(uniq)
         self.sample_to_row = np.array([pos[r] for r in rx], dtype=np.int64)
         self.labels = np.array(lab, dtype=np.int64)
-        self.T = int(chunk_size)
+        self.chunk_range = tuple(int(v) for v in chunk_range) if chunk_range is not None else None
+        self.T = int(chunk_size) if self.chunk_range is None else self.chunk_range[1]
         short = self.table.rows < self.T
         if short.any():
             raise AssertionError("%d utterances are shorter than the chunk size %d (reference: assert len(full_mat) >= seq_len)"
@@ -165,8 +169,14 @@ class NativeTrainLoader:
         q = queue.Queue(maxsize=self.prefetch)
         dev = self.device
         nslot = self.prefetch + 2
-        ring = [torch.empty(self.bs, F, self.T).pin_memory() for _ in range(nslot)] if dev is not None else None
+        ring = [torch.empty(self.bs * F * self.T).pin_memory() for _ in range(nslot)] if dev is not None else None
         copied = [None] * nslot          # per slot: event recorded after the H2D copy that last read the slot
+        if self.chunk_range is not None:
+            from .datasets import chunk_length_schedule
+            lens = chunk_length_schedule(self.chunk_range[0], self.chunk_range[1], self.chunk_range[2], len(self) + 1, self.seed,
+                                         self.epoch)
+        else:
+            lens = None
 
         def producer():
             try:
@@ -176,16 +186,17 @@ class NativeTrainLoader:
                     if len(sel) < self.bs and self.drop_last:
                         break
                     rows = self.sample_to_row[sel]
-                    starts = [int(rng.randint(0, int(self.table.rows[r]) - self.T + 1)) for r in rows]   # datasets.py:66
+                    T = self.T if lens is None else int(lens[k])          # one chunk length per batch
+                    starts = [int(rng.randint(0, int(self.table.rows[r]) - T + 1)) for r in rows]   # datasets.py:66
                     slot = k % nslot
                     if ring is not None:
                         ev = copied[slot]
                         if ev is not None:
                             ev.synchronize()            # the device has finished reading this pinned buffer
-                        buf = ring[slot][:len(sel)]
+                        buf = ring[slot][:len(sel) * F * T].view(len(sel), F, T)
                     else:
-                        buf = torch.empty(len(sel), F, self.T)
-                    self.table.read_crop(rows, starts, self.T, buf, self.threads)
+                        buf = torch.empty(len(sel), F, T)
+                    self.table.read_crop(rows, starts, T, buf, self.threads)
                     q.put((slot, buf, torch.from_numpy(self.labels[sel])))
                     k += 1
                 q.put(None)

@@ -6,8 +6,8 @@ import os
 import torch
 
 from . import hip, tiling
-from .hip import (CONV_PIPE, CONV_WS, WGRAD_GROUPS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU, EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE,
-                  MASK_RAW,
+from .hip import (CONV_PIPE, CONV_WS, DY_PRESPLIT, IN_PRESPLIT, SIDE_PRESPLIT, WGRAD_GROUPS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU,
+                  EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE, MASK_RAW,
                   call, ptr, stream)
 
 BN_EPS = 1e-5
@@ -76,16 +76,34 @@ def _amax_fwd_fallback(x, in_affine):
     return affine_estimate(in_affine[0], in_affine[1], slot, torch.zeros(1, device=x.device, dtype=torch.int32))
 
 
+def bnbwd_estimate(coef, bn4, amax_in, raw_amax, est=None):
+    """est = float bits of the rigorous bound of the BatchNorm-backward values k1 (dz - m1 - xhat m2) (spk_bnbwd_estimate):
+    coef [3][C] rows of bn_bwd_coef, bn4 = [mean, invstd, ...] rows, amax_in / raw_amax = slots with absmax(incoming gradient)
+    / absmax(raw tensor).  The value bn_bwd_coef(est_out=) produces without this launch."""
+    if est is None:
+        est = torch.zeros(1, device=coef.device, dtype=torch.int32)
+    call("spk_bnbwd_estimate", ptr(coef), ptr(bn4[0]), ptr(bn4[1]), coef.shape[1], ptr(amax_in), ptr(raw_amax), ptr(est), stream())
+    return est
+
+
 def _amax_fallback(dy, in_bnbwd):
     """Operand-scale input of a data gradient called without one (tests, tools): absmax(dy), or for the fused
-    BatchNorm-backward form the same estimate bn_bwd_coef(est_out=) gives, from absmax(dy) and the coefficient rows."""
+    BatchNorm-backward form the same bound bn_bwd_coef(est_out=) gives, from absmax(dy), absmax(raw) and the coefficient rows."""
     slot = torch.zeros(1, device=dy.device, dtype=torch.int32)
     absmax_into(dy, slot)
     if in_bnbwd is None:
         return slot
-    est = torch.zeros(1, device=dy.device, dtype=torch.int32)
-    call("spk_bnbwd_estimate", ptr(in_bnbwd[3]), in_bnbwd[3].shape[1], ptr(slot), ptr(est), stream())
-    return est
+    raw_slot = absmax_into(in_bnbwd[0], torch.zeros(1, device=dy.device, dtype=torch.int32))
+    return bnbwd_estimate(in_bnbwd[3], in_bnbwd[2], slot, raw_slot)
+
+
+def f16_window_count(x, slot, counts, affine=None, pairs=False):
+    """counts [4] int64 += (values, saturating, low term lost, high term subnormal) of x - or of relu(x*scale+shift) when
+    affine = (scale, shift); pairs: x is an f16 pair tensor - under the operand scale of `slot` (spk_f16_window_count)."""
+    C = x.shape[-1]
+    call("spk_f16_window_count", ptr(x), ptr(affine[0]) if affine else None, ptr(affine[1]) if affine else None, x.numel(), C,
+         ptr(slot), 1 if pairs else 0, ptr(counts), stream())
+    return counts
 
 
 def conv_out_hw(h, w, ksize, stride):
@@ -215,7 +233,8 @@ class PackTable:
 
 
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
-                 bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None, in_amax=None, out_amax=None, side_amax=None):
+                 bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None, in_amax=None, out_amax=None, side_amax=None,
+                 in_presplit=False, side_presplit=False):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
     dys = [t[0] for t in taps]
@@ -226,16 +245,19 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         ips, IS = IS, 1          # strided 1x1: address the input through a strided view, stage only the pixels used
     key = (OH, OW, IS, max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1, len(taps), Cout)
     if tiling.AUTOTUNE and key not in (tiling.FORCE_CONV_SPLIT if split else tiling.FORCE_CONV) and PROFILE is None and not torch.cuda.is_current_stream_capturing():
-        _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split)
+        _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split,
+                       in_amax=in_amax, in_presplit=in_presplit)
     TH, TW, MT, NT = tiling.conv_tile(*key, mode=1 if in_bnbwd is not None else 0, split=split)
     # Producer / consumer (wave-specialised, persistent) kernel for the bf16-split 3x3 launches (csrc/conv_ws_kernel.h) with
     # its own wave layouts and tiles; everything else stays on conv_mfma_kernel.
     ws, WC = None, 1
     # fused BatchNorm backward with the mask as sign bits on <= 128 output channels: optionally the in-wave pipelined kernel
     pipe_fused = (PIPE_CONV and PIPE_BNBWD and split == 3 and in_bnbwd is not None and len(in_bnbwd) > 4 and MT * NT <= 4
-                  and Cout <= 128 and WS_FORCE is None and WS_CONV != "1")
-    ws_on = WS_CONV == "1" or WS_FORCE is not None or (
-        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT and not pipe_fused)
+                  and Cout <= 128 and WS_FORCE is None and WS_CONV != "1" and not side_presplit)
+    ws_on = (WS_CONV == "1" or WS_FORCE is not None or (
+        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT and not pipe_fused))
+    if side_presplit or in_presplit:
+        ws_on = False            # f16 pair tensors: conv_mfma_kernel / conv_pipe_kernel only
     if split and ws_on and len(taps) >= WS_MIN_TAPS and ips == 1:
         ws = WS_FORCE or tiling.ws_tile(*key)
     if ws is not None:
@@ -261,6 +283,12 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
         flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
     if in_affine is not None:
         flags |= IN_AFFINE_RELU
+    if in_presplit:
+        assert split == 3 and in_affine is None and in_bnbwd is None, "f16 pair input: f16x3 mode, plain input"
+        flags |= IN_PRESPLIT
+    if side_presplit:
+        assert split == 3 and in_bnbwd is not None, "f16 pair side output: fused BatchNorm-backward data gradient in the f16x3 mode"
+        flags |= SIDE_PRESPLIT
     if epi_affine is not None:
         flags |= EPI_AFFINE
     if epi_add is not None:
@@ -300,7 +328,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
          stream(),
          label=(("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
-                else ("conv_pipe_kernel<%d,%d,false,false>" % (MT, NT) if in_bnbwd is None else "conv_pipe_kernel<%d,%d,true,true>" % (MT, NT)) if pipe
+                else ("conv_pipe_kernel<%d,%d,false,false%s>" % (MT, NT, ",true" if in_presplit else "") if in_bnbwd is None
+                      else "conv_pipe_kernel<%d,%d,true,true>" % (MT, NT)) if pipe
                 else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split)) + (
              " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * len(taps),
@@ -326,9 +355,13 @@ def _time_launch(fn, reps=2):
     return e0.elapsed_time(e1) / reps
 
 
-def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split=0):
-    """Time candidate tiles on the real operands (scratch output) and pin the fastest for this launch shape."""
+def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, split=0,
+                   in_amax=None, in_presplit=False):
+    """Time candidate tiles on the real operands (scratch output) and pin the fastest for this launch shape.  The operand-scale
+    slot is the caller's (or computed ONCE here): no absmax pass or allocation inside a timed candidate."""
     scratch = torch.empty_like(out)
+    if split == 3 and in_amax is None:
+        in_amax = _amax_fwd_fallback(x, in_affine)
     add = epi_add if (epi_add is None or epi_add.data_ptr() != out.data_ptr()) else scratch
     best = None
     table = tiling.FORCE_CONV_SPLIT if split else tiling.FORCE_CONV
@@ -336,7 +369,8 @@ def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_af
         table[key] = cand
         try:
             ms = _time_launch(lambda: _conv_launch(x, wpk, scratch, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine,
-                                                   epi_affine, add, relu, True, split=split))
+                                                   epi_affine, add, relu, True, split=split, in_amax=in_amax,
+                                                   in_presplit=in_presplit))
         except RuntimeError:
             continue
         if best is None or ms < best[0]:
@@ -347,13 +381,15 @@ def _autotune_conv(key, x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_af
         table[key] = best[1]
 
 
-def _autotune_wgrad(key, x, dy, ksize, stride, in_affine):
+def _autotune_wgrad(key, x, dy, ksize, stride, in_affine, dy_amax=None, x_amax=None, dy_presplit=False):
+    """(the operand-scale slots come from the caller: computed once, outside the timed candidates)"""
     scratch = torch.empty(dy.shape[3], x.shape[3], ksize, ksize, device=x.device, dtype=torch.float32)
     best = None
     for cand in tiling.wgrad_candidates(*key):
         tiling.FORCE_WGRAD[key] = cand
         try:
-            ms = _time_launch(lambda: conv_wgrad(x, dy, scratch, ksize, stride, in_affine=in_affine))
+            ms = _time_launch(lambda: conv_wgrad(x, dy, scratch, ksize, stride, in_affine=in_affine, dy_amax=dy_amax,
+                                                 x_amax=x_amax, dy_presplit=dy_presplit))
         except RuntimeError:
             continue
         if best is None or ms < best[0]:
@@ -385,7 +421,7 @@ def conv_fwd(x, wpk, Cout, ksize, stride, in_affine=None, epi_affine=None, epi_a
 
 
 def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumulate=False, bn_bwd=None, in_bnbwd=None,
-               side=None, add_mask=None, in_amax=None, out_amax=None, side_amax=None):
+               side=None, add_mask=None, in_amax=None, out_amax=None, side_amax=None, in_presplit=False, side_presplit=False):
     """Data gradient of conv_fwd: dy [B][OH][OW][Cout] -> dx [B][IH][IW][Cin].
     `add` (same shape as dx) is summed in the epilogue (only where the bits of `add_mask`, sign-mask words of the same
     shape, are set when that is given); accumulate=True adds onto the existing `out`.
@@ -397,8 +433,11 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
     f16x3 operand mode: in_amax = 1-element int32 tensor with the float bits of absmax(staged tensor) - for in_bnbwd an upper
     estimate of the BatchNorm-backward values (bn_bwd_coef(..., est_out=)) - that fixes the power-of-two operand scale; when
     omitted it is computed here with an extra pass (tests / tools; the engine always passes it).  out_amax / side_amax: slots
-    the launch atomically maxes |dx| / |draw_out| into (float bits) for the kernels that consume those tensors."""
+    the launch atomically maxes |dx| / |draw_out| into (float bits) for the kernels that consume those tensors.
+    in_presplit: `dy` is an f16 pair tensor (bn_backward(pair_scale=)) scaled by the sigma of in_amax, staged by plain copy.
+    side_presplit (with in_bnbwd): draw_out leaves as an f16 pair tensor scaled by the sigma of in_amax (the rigorous bound)."""
     B, OH, OW, Cout = dy.shape
+    assert not in_presplit or in_amax is not None, "an f16 pair tensor comes with its scale slot"
     if split_for(ksize, True) == 3 and in_amax is None:
         in_amax = _amax_fallback(dy, in_bnbwd)
     IH, IW = in_hw
@@ -415,7 +454,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             taps = [(0, 0, 0)]
         st = _conv_launch(dy, wpk_t, out, Cin, taps, 1, 1, 0, 0, IH, IW, None, None, add, False, False, bn_bwd, in_bnbwd,
                           side, split=split_for(ksize, True), add_mask=add_mask, in_amax=in_amax, out_amax=out_amax,
-                          side_amax=side_amax)
+                          side_amax=side_amax, in_presplit=in_presplit, side_presplit=side_presplit)
         return (out, st) if bn_bwd is not None else out
     assert stride == 2 and bn_bwd is None and in_bnbwd is None and add_mask is None
     if ksize == 1:
@@ -426,7 +465,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
             else:
                 out.zero_()
         _conv_launch(dy, wpk_t, out, Cin, [(0, 0, 0)], 1, 2, 0, 0, (IH + 1) // 2, (IW + 1) // 2, None, None, out, False,
-                     False, split=split_for(1, True), in_amax=in_amax, out_amax=out_amax)
+                     False, split=split_for(1, True), in_amax=in_amax, out_amax=out_amax, in_presplit=in_presplit)
         return out
     for cy in range(2):
         for cx in range(2):
@@ -442,7 +481,7 @@ def conv_dgrad(dy, wpk_t, Cin, ksize, stride, in_hw, add=None, out=None, accumul
                         continue
                     taps.append(((cy + 1 - kh) // 2, (cx + 1 - kw) // 2, kh * 3 + kw))
             _conv_launch(dy, wpk_t, out, Cin, taps, 1, 2, cy, cx, LH, LW, None, None, add, False, False, split=split_for(3, True),
-                         in_amax=in_amax, out_amax=out_amax)
+                         in_amax=in_amax, out_amax=out_amax, in_presplit=in_presplit)
     return out
 
 
@@ -474,12 +513,14 @@ def _workspace_named(name, nbytes, device):
     return w
 
 
-def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None):
+def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_amax=None, x_amax=None, dy_presplit=False):
     """dw (OIHW view, contiguous) <- weight gradient of conv(x) given dy.  f16x3 operand mode: dy_amax = slot with the float
-    bits of absmax(dy) (computed here with an extra pass when omitted: tests / tools)."""
+    bits of absmax(dy) (computed here with an extra pass when omitted: tests / tools).  dy_presplit: dy is an f16 pair tensor
+    scaled by the sigma of dy_amax (its scale slot), staged by plain copy."""
     B, IH, IW, Cin = x.shape
     _, OH, OW, Cout = dy.shape
     split = split_for(ksize, True)
+    assert not dy_presplit or (split == 3 and dy_amax is not None), "an f16 pair tensor comes with its scale slot (f16x3 mode)"
     if split == 3 and dy_amax is None:
         dy_amax = absmax_into(dy, torch.zeros(1, device=dy.device, dtype=torch.int32))
     if split == 3 and x_amax is None:
@@ -487,16 +528,16 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     wkey = (OH, OW, Cin, Cout, ksize, stride)
     if tiling.AUTOTUNE and wkey not in tiling.FORCE_WGRAD and PROFILE is None and not torch.cuda.is_current_stream_capturing():
         tiling.FORCE_WGRAD[wkey] = tiling._wgrad_tile(*wkey)      # placeholder: stops the recursion below
-        _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine)
+        _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine, dy_amax, x_amax, dy_presplit)
     TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split)
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
     # producer / consumer kernel (csrc/conv_wgrad_split.hip: conv_wgrad_ws_kernel): f16x3 3x3 launches whose two LDS slots fit
     halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
-    wgws = (WS_WGRAD and split == 3 and ksize == 3
+    wgws = (WS_WGRAD and split == 3 and ksize == 3 and not dy_presplit
             and 2 * (halo * 192 + -(-(TH * TW) // 16) * 16 * (WN * 192 + (64 if WN > 1 else 0))) <= 160 * 1024)
     # in-wave pipelined kernel (csrc/conv_wgrad_pipe.hip): two planar LDS slots of 64-byte rows
     nst = -(-(TH * TW) // 16)                                   # k-steps of the tile: one or two per wave group
-    wgp = (PIPE_WGRAD and not wgws and split == 3 and ksize == 3 and nst % (4 // WN) == 0 and nst // (4 // WN) in (1, 2)
+    wgp = (PIPE_WGRAD and not wgws and not dy_presplit and split == 3 and ksize == 3 and nst % (4 // WN) == 0 and nst // (4 // WN) in (1, 2)
            and 2 * (2 * halo * 64 + 2 * WN * -(-(TH * TW) // 16) * 16 * 64) + 128 <= PIPE_MAX_LDS)
     # 1x1, f16x3: conv_wgrad_1x1_kernel with 2 or 4 input-channel groups per block (csrc/conv_wgrad_1x1.hip)
     cg = 0
@@ -516,6 +557,8 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0) | (CONV_PIPE if wgp else 0)
     if cg:
         flags |= WGRAD_GROUPS | ({2: 1, 4: 2}[cg] << 12)
+    if dy_presplit:
+        flags |= DY_PRESPLIT
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
@@ -603,10 +646,13 @@ def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, 
 
 
 def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,
-                partial=None, amax_out=None):
+                partial=None, amax_out=None, pair=None):
     """Full BN backward (reduce -> finalize -> apply). bn4 = [mean, invstd, scale, shift] rows.
     `partial`: (sum dz, sum dz*xhat) rows already produced by the data-gradient epilogue (EPI_BNBWD) - skips the
-    reduction pass.  Returns draw (gradient wrt the raw conv output)."""
+    reduction pass.  Returns draw (gradient wrt the raw conv output).
+    pair = (amax_in, raw_amax, est) (f16x3 mode): draw is written as an f16 PAIR tensor (include/spkhip.h) scaled by the sigma
+    of `est`, the slot the finalize fills with the rigorous bound of |draw| from amax_in (absmax of dy) and raw_amax (absmax of
+    raw): the data gradient and the weight gradient that consume draw stage it by plain copy with that slot as their scale."""
     C = raw.shape[-1]
     N = raw.numel() // C
     coef = torch.empty(3, C, device=raw.device, dtype=torch.float32)
@@ -618,23 +664,25 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     else:
         part, nblk = partial, partial.shape[0]
     call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
-         1 if accumulate else 0, ptr(_ws64(raw.device)), None, None, stream())
+         1 if accumulate else 0, ptr(_ws64(raw.device)), ptr(pair[0]) if pair else None, ptr(pair[1]) if pair else None,
+         ptr(bn4[0]) if pair else None, ptr(pair[2]) if pair else None, stream())
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
-         ptr(draw_out), ptr(dz_out), N, C, mask_mode, ptr(amax_out), stream())
+         ptr(draw_out), ptr(dz_out), N, C, mask_mode, ptr(amax_out), ptr(pair[2]) if pair else None, stream())
     return draw_out
 
 
-def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, amax_in=None, est_out=None):
+def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, amax_in=None, raw_amax=None, est_out=None):
     """BatchNorm-backward finalize only: dgamma, dbeta and the coefficient rows [gamma*invstd, mean(dz), mean(dz*xhat)].
-    amax_in + est_out (f16x3 mode): also the upper estimate of the values the fused BatchNorm-backward data gradient will
-    stage (spk_bnbwd_estimate), from the absmax of the incoming gradient."""
+    amax_in + raw_amax + est_out (f16x3 mode): also the RIGOROUS upper bound of the values the fused BatchNorm-backward data
+    gradient will stage (spk_bnbwd_estimate), from the absmax of the incoming gradient and of the raw tensor."""
     C = gamma.numel()
     coef = torch.empty(3, C, device=gamma.device, dtype=torch.float32)
+    assert est_out is None or (amax_in is not None and raw_amax is not None)
     call("spk_bn_bwd_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(bn4[1]), ptr(dgamma),
          ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), ptr(amax_in) if est_out is not None else None,
-         ptr(est_out), stream())
+         ptr(raw_amax) if est_out is not None else None, ptr(bn4[0]) if est_out is not None else None, ptr(est_out), stream())
     return coef
 
 

@@ -63,6 +63,14 @@ parser.add_argument("--max-steps", default=-1, type=int, help="stop each epoch a
 parser.add_argument("--native-reader", action="store_true",
                     help="read training batches with the native C++ ark reader (libspkio: pread of the cropped frames on a "
                          "thread pool into pinned memory) instead of Dataset/DataLoader worker processes; --dataset v1 only")
+parser.add_argument("--var-chunk", action="store_true",
+                    help="variable-length training (BASELINE configs[3]): one chunk length per batch, uniform over "
+                         "--min-chunk-size, +quantum, ... <= --max-chunk-size, seeded, identical on every rank (the reference "
+                         "parses --min-chunk-size and never reads it, scripts/train_resnet.py:237; its Dataset can draw lengths "
+                         "per sample, scripts/datasets.py:40-43, which default collation cannot batch).  Off = the reference's "
+                         "behaviour: every chunk is --max-chunk-size frames")
+parser.add_argument("--chunk-quantum", default=8, type=int, help="step between the chunk lengths of --var-chunk (one captured "
+                                                                  "hipGraph per distinct length, one shared memory pool)")
 parser.add_argument("--no-graph", action="store_true",
                     help="launch kernels eagerly instead of replaying the step as hipGraph(s); both forms overlap the "
                          "stage-bucketed gradient all-reduce with backward")
@@ -155,20 +163,32 @@ def main_worker(gpu, ngpus_per_node, args):
     DS = SequenceDataset2 if args.dataset == "v2" else SequenceDataset
     chunk = args.max_chunk_size if args.dataset == "v2" else [args.max_chunk_size]
     train_sampler = None
+    var = (args.min_chunk_size, args.max_chunk_size, args.chunk_quantum) if args.var_chunk else None
+    if var is not None:
+        assert 0 < var[0] <= var[1], "--var-chunk needs 0 < --min-chunk-size <= --max-chunk-size"
+        print("=> variable-length training: one chunk length per batch in [{}, {}] step {}".format(*var))
     if args.native_reader and args.dataset != "v2":
         from pytorch_kaldi_resnet_amd.ingest import NativeTrainLoader
         train_loader = NativeTrainLoader(args.train_list, args.utt2spkid, args.max_chunk_size, args.batch_size,
                                          rank=max(args.rank, 0), world=world, seed=args.seed or 0,
-                                         threads=max(1, args.workers), device="cuda:%d" % args.gpu)
+                                         threads=max(1, args.workers), device="cuda:%d" % args.gpu, chunk_range=var)
         train_sampler = train_loader          # set_epoch() reshuffles, like DistributedSampler
     else:
         train_dataset = DS(scp_file=args.train_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
         if args.distributed:
             train_sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, num_replicas=args.world_size,
                                                                             rank=args.rank, shuffle=True)
-        train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size,
-                                                   shuffle=(train_sampler is None), num_workers=args.workers,
-                                                   pin_memory=True, sampler=train_sampler, drop_last=False)
+        if var is not None:
+            # the chunk length rides on the index ((index, T) pairs), so worker processes need no shared state
+            from pytorch_kaldi_resnet_amd.datasets import ChunkBatchSampler
+            inner = train_sampler if train_sampler is not None else torch.utils.data.RandomSampler(train_dataset)
+            train_sampler = ChunkBatchSampler(inner, args.batch_size, var[0], var[1], var[2], seed=args.seed or 0)
+            train_loader = torch.utils.data.DataLoader(train_dataset, batch_sampler=train_sampler, num_workers=args.workers,
+                                                       pin_memory=True)
+        else:
+            train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size,
+                                                       shuffle=(train_sampler is None), num_workers=args.workers,
+                                                       pin_memory=True, sampler=train_sampler, drop_last=False)
     print("=> args.world_size: {}, args.rank: {}, args.batch_size: {}, train_loader samples: {}".format(
         args.world_size, args.rank, args.batch_size, len(train_loader)))
     val = DS(scp_file=args.cv_list, utt2spkid_file=args.utt2spkid, chunk_size=chunk)
@@ -232,7 +252,13 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
     losses, top1, top5 = DeviceMeter("Loss", ":.4e"), DeviceMeter("Acc@1", ":6.2f"), DeviceMeter("Acc@5", ":6.2f")
     model.train()
     eng = model.engine()
-    graphed = getattr(eng, "_graphed_step", None)
+    # one captured step per (batch, chunk length), one shared memory pool (engine.GraphedStepCache): a fixed-length run
+    # captures once, --var-chunk once per distinct length
+    cache = getattr(eng, "_graph_cache", None)
+    if cache is None and not args.no_graph:
+        from pytorch_kaldi_resnet_amd.engine import GraphedStepCache
+        cache = eng._graph_cache = GraphedStepCache(eng, segmented=world > 1)
+    t_enq, n_enq = 0.0, 0
     end = time.time()
     t_epoch, n_utt = time.time(), 0
     for i, (audios, target) in enumerate(loader):
@@ -241,14 +267,15 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
         dt_.update(time.time() - end)
         audios = audios.cuda(args.gpu, non_blocking=True)
         target = target.cuda(args.gpu, non_blocking=True).long()
-        if not args.no_graph and (graphed is None or not graphed.matches(audios)) and audios.size(0) == args.batch_size:
-            from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
-            graphed = eng._graphed_step = GraphedTrainStep(eng, audios.size(0), audios.size(2), segmented=world > 1)
-        if not args.no_graph and graphed is not None and graphed.matches(audios):
+        if not args.no_graph and audios.size(0) == args.batch_size:
             # hipGraph replay: weight re-pack + fwd + CE + bwd; with world > 1 six stage segments with the stage's
             # all-reduce enqueued on the communication stream between them (overlaps the remaining backward)
-            loss, _, rank = graphed(audios, target, reducer.on_stage_done if world > 1 else None)
+            known = (audios.size(0), audios.size(2)) in cache.steps
+            t_q = time.time()
+            loss, _, rank = cache(audios, target, reducer.on_stage_done if world > 1 else None)
             reducer.finish()
+            if known:
+                t_enq, n_enq = t_enq + time.time() - t_q, n_enq + 1
         else:
             optimizer.zero_grad(set_to_none=True)
             loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if world > 1 else None)
@@ -265,6 +292,9 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
             _progress("Epoch: [{}]".format(epoch), i, len(loader), [bt, dt_, losses, top1, top5])
     torch.cuda.synchronize()
     print(" * epoch {} train throughput {:.1f} utt/s (this rank)".format(epoch, n_utt / max(time.time() - t_epoch, 1e-9)))
+    if cache is not None and n_enq:
+        print(" * epoch {} captured steps: {} (chunk lengths {}), host enqueue {:.2f} ms/step over {} replays".format(
+            epoch, len(cache), sorted({k[1] for k in cache.steps}), 1e3 * t_enq / n_enq, n_enq))
 
 
 def validate(loader, model, args):

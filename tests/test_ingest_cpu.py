@@ -104,3 +104,42 @@ def test_text_vector_writer_is_byte_identical_to_numpy_str():
         assert ingest.format_text_vectors(keys, x, nthreads).decode() == ref
     one = ingest.format_text_vectors(["a"], np.array([[1.5]], dtype=np.float32))
     assert one == b"a [ 1.5 ]\n"
+
+
+def test_variable_chunk_lengths_one_per_batch_same_on_every_rank(tmp_path):
+    """BASELINE configs[3] (variable-length batches; reference scripts/datasets.py:40-43,53-57): one chunk length per batch,
+    drawn from (seed, epoch) only - identical on every rank - in the native loader and through ChunkBatchSampler + the
+    Dataset classes (the length travels with the index, so DataLoader workers need no shared state)."""
+    from pytorch_kaldi_resnet_amd.datasets import ChunkBatchSampler, SequenceDataset, chunk_length_schedule
+    scp, u2s, mats, lines = _corpus(tmp_path)
+    sched = chunk_length_schedule(16, 28, 4, 50, seed=3, epoch=0)
+    assert set(sched) <= {16, 20, 24, 28} and len(set(sched)) > 1
+    assert np.array_equal(sched, chunk_length_schedule(16, 28, 4, 50, seed=3, epoch=0))
+    assert not np.array_equal(sched, chunk_length_schedule(16, 28, 4, 50, seed=3, epoch=1))
+    # native loader: two ranks see the same length sequence, different samples; every crop is a window of its utterance
+    la = ingest.NativeTrainLoader(scp, u2s, 0, 4, rank=0, world=2, seed=3, chunk_range=(16, 28, 4))
+    lb = ingest.NativeTrainLoader(scp, u2s, 0, 4, rank=1, world=2, seed=3, chunk_range=(16, 28, 4))
+    ta = [x.shape[2] for x, _ in la]
+    tb = [x.shape[2] for x, _ in lb]
+    assert ta == tb == [int(t) for t in sched[:len(ta)]] and len(ta) == len(la)
+    allm = list(mats.values())
+    for x, y in la:
+        T = x.shape[2]
+        assert x.is_contiguous()
+        for i in range(x.shape[0]):
+            w = x[i].numpy().T
+            assert any(any(np.array_equal(w, m[s:s + T]) for s in range(m.shape[0] - T + 1)) for m in allm)
+        break
+    la.set_epoch(1)
+    assert [x.shape[2] for x, _ in la] != ta
+    with pytest.raises(AssertionError):                                   # utterances shorter than the longest chunk
+        ingest.NativeTrainLoader(scp, u2s, 0, 4, chunk_range=(16, 60, 4))
+    # Dataset + batch sampler (DataLoader path), with worker processes
+    ds = SequenceDataset(scp, u2s, [28])
+    bs = ChunkBatchSampler(torch.utils.data.SequentialSampler(ds), 4, 16, 28, 4, seed=3)
+    dl = torch.utils.data.DataLoader(ds, batch_sampler=bs, num_workers=2)
+    shapes = [tuple(x.shape) for x, _ in dl]
+    assert [s[2] for s in shapes] == [int(t) for t in chunk_length_schedule(16, 28, 4, len(bs), 3, 0)]
+    assert all(s[1] == 12 for s in shapes) and sum(s[0] for s in shapes) == len(ds)
+    # a plain int index still means "the dataset's own chunk length"
+    assert ds[0][0].shape == (12, 28)

@@ -126,16 +126,10 @@ def hip_step_with_masks(m, xg, yg):
     m.attach_grads()
     for p in m.parameters():
         p.grad = None
+    from helpers import hip_relu_masks
     with torch.no_grad():
         logits, saved = eng.forward_train(xg.contiguous(), yg)
-        nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()      # noqa: E731
-        masks = [nchw(saved["blocks"][0]["x"])]
-        for b, rec in zip(eng.blocks, saved["blocks"]):
-            for raw, bn in zip(rec["raws"][:-1], b.bns[:-1]):
-                masks.append(nchw(ops.bn_apply(raw, bn.t4[2], bn.t4[3], relu=True)))
-            masks.append(nchw(rec["out"]))
-        if "h" in saved["head"]:
-            masks.append((saved["head"]["h"] > 0).cpu())
+        masks = hip_relu_masks(eng, saved)
         loss_row, dl, _ = ops.softmax_ce(logits, yg, grad_scale=1.0 / logits.shape[0])
         loss = float(ops.mean(loss_row))
     eng.backward(saved, dl)

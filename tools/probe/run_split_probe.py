@@ -26,10 +26,25 @@ for name, K, mk in (("relu-act x N(0,.03) weights, K=4608", 4608, lambda K: (tor
         err = (C.cpu().double() - ref).abs()
         print("  %-27s max %.3e rms %.3e (rc %d)" % (lab, float(err.max() / scale), float(err.pow(2).mean().sqrt() / scale), rc))
 
-# fp16 denormal operands: does the matrix instruction keep them?  a = 2^-20 (subnormal in fp16) x b = 1 over K = 16
-A = torch.zeros(32, 16); A[:, 0] = 2.0 ** -20
-B = torch.zeros(16, 32); B[0, :] = 1.0
-C = torch.zeros(32, 32, device="cuda")
-lib.split_probe(A.cuda().data_ptr(), B.cuda().data_ptr(), C.data_ptr(), 16, 23, 1, torch.cuda.current_stream().cuda_stream, 1.0, 1.0)
-torch.cuda.synchronize()
-print("fp16 subnormal operand 2^-20 x 1 -> %.6e (exact %.6e): %s" % (float(C[0, 0]), 2.0 ** -20, "kept" if float(C[0, 0]) != 0 else "FLUSHED"))
+# fp16 SUBNORMAL operands: does v_mfma_f32_32x32x16_f16 keep them or flush them to zero?  Operands are built from bit patterns
+# inside the kernel (the round-2 version of this check passed pointers of temporaries that had already been freed - it printed
+# 1.0 for 2^-20 x 1 - and is replaced by this one).  fp16: min normal 2^-14 = 0x0400, subnormals 2^-24 (0x0001) .. 2^-15 (0x0200).
+import numpy as np
+lib.subnormal_probe.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+out = torch.zeros(1, device="cuda")
+ONE = 0x3C00
+kept_all = True
+for name, bits in (("2^-24 (smallest subnormal)", 0x0001), ("2^-20 (subnormal)", 0x0010), ("2^-15 (largest power-of-two subnormal)", 0x0200),
+                   ("2^-14 (smallest normal)", 0x0400), ("1.5 * 2^-16 (subnormal, two mantissa bits)", 0x0180)):
+    exact = float(np.array([bits], dtype=np.uint16).view(np.float16)[0])
+    res = []
+    for a, b in ((bits, ONE), (ONE, bits)):
+        out.zero_()
+        lib.subnormal_probe(a, b, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res.append(float(out[0]))
+    ok = all(r == exact for r in res)
+    if bits < 0x0400:
+        kept_all = kept_all and ok
+    print("fp16 operand %-44s as A: %.6e  as B: %.6e  (exact %.6e): %s" % (name, res[0], res[1], exact, "kept" if ok else ("FLUSHED" if all(r == 0 for r in res) else "ALTERED")))
+print("=> v_mfma_f32_32x32x16_f16 %s fp16 subnormal operands" % ("KEEPS" if kept_all else "does NOT keep"))

@@ -99,3 +99,22 @@ extern "C" int split_probe(const float* A, const float* B, float* C, int K, int 
     hipLaunchKernelGGL(split_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C, K, variant, reps, sa, sb);
     return (int)hipGetLastError();
 }
+
+
+// fp16 subnormal operands of v_mfma_f32_32x32x16_f16: C[i][j] = sum_k A[i][k] B[k][j] with A[i][0] = the fp16 whose bits are
+// a_bits (other k: 0) and B[0][j] = the fp16 whose bits are b_bits.  Operands are built from BIT PATTERNS (no conversion
+// instruction in between that could flush), the accumulator is fp32: out[0] = C[0][0].
+__global__ void subnormal_probe_kernel(unsigned short a_bits, unsigned short b_bits, float* out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    s16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = 0; b[i] = 0; }
+    if (h == 0) { a[0] = (short)a_bits; b[0] = (short)b_bits; }      // k = 8 h + 0
+    f32x16 acc;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    if (lane == 0) out[0] = acc[0];
+}
+extern "C" int subnormal_probe(unsigned a_bits, unsigned b_bits, float* out, void* stream) {
+    hipLaunchKernelGGL(subnormal_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned short)a_bits, (unsigned short)b_bits, out);
+    return (int)hipGetLastError();
+}
