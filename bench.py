@@ -532,6 +532,26 @@ def main():
                               args.ingest_utts, args.frames, args.frames + 31, FEAT, ark_bytes / 1e6)}
         log("ingest-inclusive: %.1f utt/s (%.3f of the resident-input rate)" % (ingest["value"], ingest["ratio_to_resident_input"]))
 
+    f16_window = None
+    if rank == 0 and args.mode == "train" and ops.SPLIT == 3 and not args.no_f16_window:
+        # one eager step (outside every timed region) with the window counters on: every tensor an f16x3 matrix-core kernel
+        # stages is also run through spk_f16_window_count under the scale slot its consumer uses
+        eng.window_counts = torch.zeros(4, device=dev, dtype=torch.int64)
+        opt.zero_grad(set_to_none=True)
+        eng.loss_and_grad(x if var_x is None else var_x[sorted(var_x)[0]], y, None)
+        torch.cuda.synchronize()
+        tot, sat, lo_lost, hi_sub = eng.window_counts.tolist()
+        eng.window_counts = None
+        opt.zero_grad(set_to_none=True)
+        f16_window = {"staged_values": tot, "saturated": sat, "low_term_lost_frac": round(lo_lost / max(tot, 1), 8),
+                      "high_term_subnormal_frac": round(hi_sub / max(tot, 1), 8),
+                      "note": "values staged by f16x3 matrix-core kernels in one step, judged under the scale slot of their consumer "
+                              "(absmax of the tensor or a rigorous bound): saturated must be 0; a lost low term = the value is "
+                              "carried with 11 instead of 22 significand bits (absolute error <= bound * 2^-29)"}
+        log("f16 windows: %d staged values, %d saturated, %.5f %% low term lost" % (tot, sat, 100.0 * lo_lost / max(tot, 1)))
+        if sat:
+            raise SystemExit("bench: %d staged values saturate fp16 under their scale slot - an operand-scale bound is wrong" % sat)
+
     roofline = None
     if rank == 0 and not args.no_roofline and args.mode == "train":
         # instrumented pass: same steps, every launch bracketed by HIP events on its launch stream; the side stream
@@ -680,7 +700,7 @@ def main():
             "graph_replay_repacks_weights": repack_ok, "eer": eer,
             "kernel_launches_per_step": (sum(v["launches_per_step"] for v in roofline["all_kernels"].values())
                                          if roofline else None),
-            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native, "ingest": ingest,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native, "ingest": ingest, "f16_window": f16_window,
             "embedding_cosine_delta_vs_oracle": parity,
         }
         print(json.dumps(out))

@@ -97,7 +97,8 @@ int spk_pack_conv_weights_batched(const void* jobs, int njobs, int total_blocks,
  * values, written by the kernel that produced the tensor, or a rigorous upper bound of it (spk_bn_finalize est_out for a fused
  * input BatchNorm+ReLU, spk_bn_bwd_finalize est_out for a fused BatchNorm backward) - so that the largest staged magnitude
  * lands in [2^14, 2^15) and nothing can saturate), three cross products on v_mfma_f32_32x32x16_f16, fp32 accumulation,
- * accumulators scaled back by 1/(sigma_in * sigma_w).  Values below bound * 2^-17 lose the low term (carried with 11 bits).
+ * accumulators scaled back by 1/(sigma_in * sigma_w).  Values below bound * 2^-18 have a subnormal low term (the instruction
+ * keeps fp16 subnormals: absolute error <= bound * 2^-39, relative precision falling from 22 to 11 bits at bound * 2^-28).
  * Measured accuracy = the fp32 instruction's (tools/probe/split_probe.hip).  out_amax / side_amax (optional, any split): the
  * launch atomically maxes the float bits of |stored output| / |side_draw| into them - the in_amax of the kernels that consume
  * those tensors (side_amax records the true absmax also when side_draw leaves as an f16 pair tensor).
@@ -192,8 +193,8 @@ int spk_absmax(const float* x, unsigned* slot, long long n, void* stream);
 int spk_bnbwd_estimate(const float* coef, const float* mean, const float* invstd, int C, const unsigned* amax_in,
                        const unsigned* raw_amax, unsigned* est, void* stream);
 /* diagnostics of the f16x3 windows (debug / tests, never on the training path): counts[0] += values looked at, [1] += values
- * that saturate fp16 under the slot's scale (must stay 0), [2] += values whose low term is an fp16 subnormal (carried with 11
- * significand bits), [3] += values whose high term is subnormal.  The values are x (n floats, n % 4 == 0), or
+ * that saturate fp16 under the slot's scale (must stay 0), [2] += values whose low term is an fp16 subnormal (kept by the
+ * matrix instruction: 11..22 significand bits, absolute error <= bound * 2^-39), [3] += values whose high term is subnormal.  The values are x (n floats, n % 4 == 0), or
  * max(x*scale[c]+shift[c], 0) with c = index % C when scale / shift are given, or - pairs != 0 - the stored terms of an f16
  * pair tensor. */
 int spk_f16_window_count(const float* x, const float* scale, const float* shift, long long n, int C, const unsigned* slot,

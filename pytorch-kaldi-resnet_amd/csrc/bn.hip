@@ -556,9 +556,9 @@ extern "C" int spk_bnbwd_estimate(const float* coef, const float* mean, const fl
 
 // ---- f16x3 diagnostics: how a tensor sits in the two-term fp16 window of its scale slot ------------------------------------
 // counts[0] += values looked at, [1] += values that SATURATE (|v sigma| > 65504: must be 0, every slot is an absmax or a rigorous
-// bound), [2] += values whose low term is lost (0 < |lo| < 2^-14: fp16 subnormal, flushed by the matrix instruction - the
-// value is carried with 11 significand bits, an absolute error <= bound * 2^-29), [3] += values whose HIGH term is subnormal
-// (|v sigma| < 2^-14: carried as zero, absolute error <= bound * 2^-28).  v = x, or max(x*scale[c]+shift[c], 0) when scale is
+// bound), [2] += values whose low term is an fp16 subnormal (0 < |lo| < 2^-14: kept by the matrix instruction with an absolute
+// resolution of 2^-24 - the value carries between 11 and 22 significand bits, absolute error <= bound * 2^-39), [3] += values
+// whose HIGH term is subnormal (|v sigma| < 2^-14: fewer than 11 bits, same absolute error bound).  v = x, or max(x*scale[c]+shift[c], 0) when scale is
 // given (what a convolution with the fused input BatchNorm+ReLU stages); pairs != 0: x is an f16 pair tensor (the window
 // is then read back from the stored terms; a stored high term of +-65504 counts as saturated).  Debug / test export: never
 // on the training path.

@@ -142,7 +142,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int n0 = cg * NT * 32;
     const int flags = a.flags;
 
-    int lbase[MT], obase[MT];
+    int lbase[MT], obase[MT], opix[MT];      // opix: output pixel index (the masks are addressed per pixel)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int q = (wave * MT + i) * 32 + r;
@@ -152,7 +152,8 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         const int oy = oy0 + ly, ox = ox0 + lx;
         v = v && oy < a.OH && ox < a.OW;
         lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + h;   // 16-byte units
-        obase[i] = v ? ((b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox) * a.Cout + n0 : -1;
+        opix[i] = (b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox;
+        obase[i] = v ? opix[i] * a.Cout + n0 : -1;
     }
 
     f32x16 acc[MT][NT];
@@ -728,69 +729,210 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     }
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
     float out_mx = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
-            }
-        // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
-#pragma unroll
-        for (int k = 0; k < 32 / RPP; ++k) {
-            const int row = k * RPP + qr;
-            const int ob = __shfl(obase[i], row, 64);
-            f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
-#ifdef ABL_NO_EPI
-            asm volatile("" ::"v"(v));
-            if (ob == -12345) {
-#else
-            if (ob >= 0) {
+#ifndef SPK_EPI_BATCH
+#define SPK_EPI_BATCH 1      // 0: A/B builds with the pass-by-pass epilogue everywhere (tools/variant.sh)
 #endif
-                float* dst = a.out + ob + qc * 4;
-                if (flags & SPK_EPI_AFFINE) v = v * es + eh;
-                if (flags & SPK_EPI_ADD) {
-                    f32x4 ad = *(const f32x4*)(a.epi_add + ob + qc * 4);
-                    if (a.add_mask) {
-                        const int ch0 = n0 + qc * 4;
-                        const unsigned bits = a.add_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
+    // Which instantiations batch their epilogue reads (below): the data gradients - the fused BatchNorm-backward form of
+    // conv_mfma_kernel and the pair-input form of conv_pipe_kernel - whose launches always carry the shortcut add and / or the
+    // BatchNorm-backward statistics.  The forward instantiations keep the pass-by-pass form: they have no epilogue reads, the
+    // batch costs registers (84 -> 126 on the 32-channel forward kernel: one wave per SIMD less on an HBM-bound kernel,
+    // measured +30 % time), and conv_pipe_kernel with conversion while staging sits at its 256-register launch bound.
+    constexpr bool EPB = SPK_EPI_BATCH && (PRE || (BNBWD && !PIPE));
+    if constexpr (!EPB) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) ad[c] = ((bits >> c) & 1u) ? ad[c] : 0.f;
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
+                }
+            // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
+#pragma unroll
+            for (int k = 0; k < 32 / RPP; ++k) {
+                const int row = k * RPP + qr;
+                const int ob = __shfl(obase[i], row, 64);
+                f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
+#ifdef ABL_NO_EPI
+                asm volatile("" ::"v"(v));
+                if (ob == -12345) {
+#else
+                if (ob >= 0) {
+#endif
+                    float* dst = a.out + ob + qc * 4;
+                    if (flags & SPK_EPI_AFFINE) v = v * es + eh;
+                    if (flags & SPK_EPI_ADD) {
+                        f32x4 ad = *(const f32x4*)(a.epi_add + ob + qc * 4);
+                        if (a.add_mask) {
+                            const int ch0 = n0 + qc * 4;
+                            const unsigned bits = a.add_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) ad[c] = ((bits >> c) & 1u) ? ad[c] : 0.f;
+                        }
+                        v += ad;
                     }
-                    v += ad;
-                }
-                if (flags & SPK_EPI_RELU) {
-                    v[0] = fmaxf(v[0], 0.f);
-                    v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f);
-                    v[3] = fmaxf(v[3], 0.f);
-                }
-                *(f32x4*)dst = v;
-                out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                if (flags & SPK_EPI_BNBWD) {
-                    // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
-                    // its backward needs no separate reduction pass over this tensor
-                    const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
-                    f32x4 dz;
-                    if (a.bn_mask) {
-                        const int ch0 = n0 + qc * 4;
-                        const unsigned bits = a.bn_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
+                    if (flags & SPK_EPI_RELU) {
+                        v[0] = fmaxf(v[0], 0.f);
+                        v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f);
+                        v[3] = fmaxf(v[3], 0.f);
+                    }
+                    *(f32x4*)dst = v;
+                    out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    if (flags & SPK_EPI_BNBWD) {
+                        // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
+                        // its backward needs no separate reduction pass over this tensor
+                        const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
+                        f32x4 dz;
+                        if (a.bn_mask) {
+                            const int ch0 = n0 + qc * 4;
+                            const unsigned bits = a.bn_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
+                            for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
+                        } else {
+                            f32x4 m;
+                            if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
+                            else m = rw * bsc + bsh;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                        }
+                        ssum += dz;
+                        ssq += dz * ((rw - bmu) * bis);
                     } else {
-                        f32x4 m;
-                        if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
-                        else m = rw * bsc + bsh;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                        ssum += v;
+                        ssq += v * v;
                     }
-                    ssum += dz;
-                    ssq += dz * ((rw - bmu) * bis);
-                } else {
-                    ssum += v;
-                    ssq += v * v;
+                }
+            }
+        }
+    } else {
+        // The epilogue's global READS (shortcut / masked gradient add, raw tensor and mask of the fused BatchNorm-backward
+        // statistics) are issued branch-free for a whole batch of passes BEFORE the accumulators of the m-tile take their round
+        // trip through the LDS slab, from clamped addresses (a pixel outside the grid reads the tile's first pixel - always inside
+        // - and its value is dropped): one exposed memory latency per m-tile instead of a chain of one per pass (a data gradient
+        // with both fusions has 8 passes x MT m-tiles of them per wave; measured round 3: 0.40 -> see DESIGN.md).  Results are
+        // bit-identical to the pass-by-pass form (same values, same order of the per-lane statistics sums).
+        constexpr int NP = 32 / RPP;                     // passes per m-tile
+        // passes whose operands are in flight together: 4 x 11 registers, a budget that keeps the 32-channel (HBM-bound, occupancy-
+        // sensitive) instantiations at their occupancy and the large tiles under their launch bound
+        constexpr int PB = NP < 4 ? NP : 4;
+        const int pix_safe = (b * a.OHf + oy0 * a.OS + a.ooy) * a.OWf + ox0 * a.OS + a.oox;      // the tile's first pixel
+        const int cw32 = a.Cout >> 5, ch0 = n0 + qc * 4;
+        const bool f_add = (flags & SPK_EPI_ADD) != 0, f_bnb = (flags & SPK_EPI_BNBWD) != 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
+                }
+            // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
+            if (!f_add && !f_bnb) {
+                // no global reads in this epilogue (forward convolutions): pass by pass
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int row = k * RPP + qr;
+                    const int ob = __shfl(obase[i], row, 64);
+                    f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
+#ifdef ABL_NO_EPI
+                    asm volatile("" ::"v"(v));
+                    if (ob == -12345) {
+#else
+                    if (ob >= 0) {
+#endif
+                        if (flags & SPK_EPI_AFFINE) v = v * es + eh;
+                        if (flags & SPK_EPI_RELU) {
+                            v[0] = fmaxf(v[0], 0.f);
+                            v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f);
+                            v[3] = fmaxf(v[3], 0.f);
+                        }
+                        *(f32x4*)(a.out + ob + qc * 4) = v;
+                        out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        ssum += v;
+                        ssq += v * v;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < NP; k0 += PB) {
+                int obv[PB];
+                f32x4 adv[PB], rwv[PB];
+                unsigned amw[PB], bmw[PB];
+#pragma unroll
+                for (int kk = 0; kk < PB; ++kk) {
+                    const int row = (k0 + kk) * RPP + qr;
+                    const int ob = __shfl(obase[i], row, 64);
+                    const int px = __shfl(opix[i], row, 64);          // (shuffles stay outside any lane-dependent condition)
+                    obv[kk] = ob;
+                    const int pix = ob >= 0 ? px : pix_safe;
+                    const int o = pix * a.Cout + ch0;                                     // element offset of this lane's quad
+                    if (f_add) {
+                        adv[kk] = *(const f32x4*)(a.epi_add + o);
+                        if (a.add_mask) amw[kk] = a.add_mask[(size_t)pix * cw32 + (ch0 >> 5)];
+                    }
+                    if (f_bnb) {
+                        rwv[kk] = *(const f32x4*)(a.bn_raw + o);
+                        if (a.bn_mask) bmw[kk] = a.bn_mask[(size_t)pix * cw32 + (ch0 >> 5)];
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < PB; ++kk) {
+                    const int row = (k0 + kk) * RPP + qr;
+                    const int ob = obv[kk];
+                    f32x4 v = *(const f32x4*)(slab + row * LW + qc * 4);
+#ifdef ABL_NO_EPI
+                    asm volatile("" ::"v"(v));
+                    if (ob == -12345) {
+#else
+                    if (ob >= 0) {
+#endif
+                        float* dst = a.out + ob + qc * 4;
+                        if (flags & SPK_EPI_AFFINE) v = v * es + eh;
+                        if (f_add) {
+                            f32x4 ad = adv[kk];
+                            if (a.add_mask) {
+                                const unsigned bits = amw[kk] >> (ch0 & 31);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) ad[c] = ((bits >> c) & 1u) ? ad[c] : 0.f;
+                            }
+                            v += ad;
+                        }
+                        if (flags & SPK_EPI_RELU) {
+                            v[0] = fmaxf(v[0], 0.f);
+                            v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f);
+                            v[3] = fmaxf(v[3], 0.f);
+                        }
+                        *(f32x4*)dst = v;
+                        out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        if (f_bnb) {
+                            // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
+                            // its backward needs no separate reduction pass over this tensor
+                            const f32x4 rw = rwv[kk];
+                            f32x4 dz;
+                            if (a.bn_mask) {
+                                const unsigned bits = bmw[kk] >> (ch0 & 31);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
+                            } else {
+                                f32x4 m;
+                                if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);      // (activated tensor instead of mask bits: tests / tools)
+                                else m = rw * bsc + bsh;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
+                            }
+                            ssum += dz;
+                            ssq += dz * ((rw - bmu) * bis);
+                        } else {
+                            ssum += v;
+                            ssq += v * v;
+                        }
+                    }
                 }
             }
         }

@@ -304,7 +304,7 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     SPK_REQUIRE(split == 0 || split == 3 || ((split == 6 || split == 9) && ksize == 3),
                 "spk_conv_wgrad: split=%d (0; 3 = f16x3, any kernel size; 6 / 9 = bf16 terms, 3x3 only)", split);
     // f16x3: both operand scales ALWAYS come from slots (a NULL dy_amax meant scale 1 - typical gradients of 1e-5..1e-8
-    // then became fp16 subnormals, flushed by the matrix instruction: dw silently ~0)
+    // then sat in or below fp16's subnormal range - a handful of significand bits at best: dw silently wrong)
     SPK_REQUIRE(split != 3 || (dy_amax && x_amax), "spk_conv_wgrad: the f16x3 operand mode needs dy_amax and x_amax (slots with the float bits of the operands' absmax or of upper bounds)");
     SPK_REQUIRE(!(flags & SPK_DY_PRESPLIT) || (split == 3 && !(flags & (SPK_CONV_PIPE | SPK_CONV_WS))),
                 "spk_conv_wgrad: DY_PRESPLIT (dy as an f16 pair tensor) needs the f16x3 mode (not the opt-in pipelined / wave-specialised forms)");

@@ -106,13 +106,17 @@ static __device__ __forceinline__ void spk_terms(f32x4 w, float sigma, bool pair
     if (pairs) spk_pair_unpack(w, t0, t1);
     else split2h(w, sigma, t0, t1);
 }
-// power-of-two scale from the bits of a tensor's absmax (or of an upper bound of it): amax * sigma in [2^14, 2^15), just
-// under the fp16 maximum (65504): every value >= amax * 2^-18 keeps both terms normal (22 significant bits); smaller ones
-// lose the low term (fp16 subnormals do not survive the matrix instruction) and are carried with 11 bits - an absolute
-// error <= amax * 2^-30 per element, visible only when one element outweighs the rest of its tensor by > 10^5
-// (tests/test_kernels_gpu.py::test_f16x3_precision_floor_below_the_scale_window; the bf16 modes have no such floor).  Heuristic (non-rigorous) estimates carry their
-// own headroom factor - none is left: every scale now comes from a true absmax or from a rigorous bound
-// (bn.hip: bn_finalize_kernel for relu(raw*scale+shift), bn_bwd_finalize_kernel for the BatchNorm-backward values).
+// power-of-two scale from the bits of a tensor's absmax (or of a rigorous upper bound of it): bound * sigma in [2^14, 2^15),
+// just under the fp16 maximum (65504), so nothing can saturate.  Precision of a staged value u = v * sigma:
+//   |u| >= 2^-3  (v >= bound * 2^-18): both terms are normal fp16 numbers: 22 significand bits;
+//   below that the LOW term is an fp16 subnormal (resolution 2^-24), below 2^-14 the high term too.  v_mfma_f32_32x32x16_f16
+//   KEEPS subnormal operands (tools/probe/run_split_probe.py, profiles/r03_split_probe.log: 2^-24 ... 2^-15 come through
+//   exactly, as A and as B operand; round 2 claimed the opposite from a broken probe), and v_cvt_f16_f32 produces them,
+//   so such values are carried with an ABSOLUTE error <= 2^-25 / sigma <= bound * 2^-39 - relative precision degrades
+//   gracefully from 22 bits at bound * 2^-18 to 11 bits at bound * 2^-28 and is lost at bound * 2^-39.
+// (tests/test_kernels_gpu.py::test_f16x3_precision_floor_below_the_scale_window; the bf16 modes have fp32's exponent range.)
+// Every scale comes from a true absmax or from a rigorous bound (bn.hip: bn_finalize_kernel for relu(raw*scale+shift),
+// bn_bwd_finalize_kernel / bnbwd_bound for the BatchNorm-backward values): no heuristic and no headroom factor is left.
 static __device__ __forceinline__ float spk_sigma_from_amax_bits(unsigned bits) {
     const int e = (int)((bits >> 23) & 0xffu);            // biased exponent; amax = m * 2^(e - 127), m in [1, 2)
     if (e == 0 || e == 255) return 1.f;                   // zero / subnormal / inf / nan: no scaling

@@ -50,16 +50,22 @@ class _BN:
     def __init__(self, holder):
         self.h = holder
         self.c = holder.c
-        self.t4 = None      # train: [mean, invstd, scale, shift]
+        self.t4 = None      # train: [mean, invstd, scale, shift] of the forward whose backward is pending
+        self.s4 = None      # the same rows for a training-mode forward WITHOUT a backward (no-grad / predict in train mode)
         self.e2 = None      # eval:  [scale, shift]
 
-    def finalize(self, partial, count, amax_in=None, est_out=None):
-        if self.t4 is None:
-            self.t4 = torch.empty(4, self.c, device=partial.device, dtype=torch.float32)
+    def finalize(self, partial, count, amax_in=None, est_out=None, keep=True):
+        """keep=False: the statistics go to a scratch row set, so that a no-grad training-mode forward between forward_train
+        and backward does not overwrite what the pending backward reads (the running statistics still advance, as in the
+        reference: any train-mode forward updates them)."""
+        name = "t4" if keep else "s4"
+        if getattr(self, name) is None:
+            setattr(self, name, torch.empty(4, self.c, device=partial.device, dtype=torch.float32))
+        t4 = getattr(self, name)
         h = self.h
         ops.bn_finalize(partial, count, h.weight.data, h.bias.data, h.running_mean, h.running_var, h.num_batches_tracked,
-                        self.t4, amax_in=amax_in, est_out=est_out)
-        return self.t4
+                        t4, amax_in=amax_in, est_out=est_out)
+        return t4
 
     def eval_coeffs(self):
         h = self.h
@@ -197,8 +203,6 @@ class Engine:
             setattr(self, name, ops.AmaxPool(device))
         pool = getattr(self, name)
         pool.reset()
-        if train:
-            self._fwd_gen += 1
         return pool
 
     def _count(self, x, slot, affine=None, pairs=False):
@@ -257,7 +261,7 @@ class Engine:
             bn = self.head_bn
             if train:
                 part = ops.bn_stats_partial(emb)
-                t4 = bn.finalize(part, emb.shape[0])
+                t4 = bn.finalize(part, emb.shape[0], keep=save)
                 h = ops.bn_apply(emb, t4[2], t4[3], relu=True)
             else:
                 e2 = bn.eval_coeffs()
@@ -300,12 +304,14 @@ class Engine:
     def _trunk_train(self, x, save):
         saved = {"x": x, "blocks": []}
         pool = self._fwd_pool(x.device, train=save)
-        saved["amax_gen"] = self._fwd_gen
+        if save:
+            self._fwd_gen += 1                 # this forward now owns the per-engine records (BN statistics rows, scale slots)
+        saved["gen"] = self._fwd_gen
         take = (lambda: pool.take()) if pool is not None else (lambda: None)
         f16 = ops.split_for(3) == 3
         raw0, st = ops.stem_fwd(x, self.stem_conv.h.weight.data, stats=True)
         B, F, T, _ = raw0.shape
-        t4 = self.stem_bn.finalize(st, B * F * T)
+        t4 = self.stem_bn.finalize(st, B * F * T, keep=save)
         use_masks = save and self.use_sign_masks
         a_amax = take()
         a = ops.bn_apply(raw0, t4[2], t4[3], relu=True, mask=use_masks, amax_out=a_amax)
@@ -327,14 +333,14 @@ class Engine:
                                        in_amax=h_amax if ops.split_for(c.k) == 3 else None, out_amax=raw_amax)
                 # the next conv stages relu(bn(raw)): its operand-scale bound comes out of the BatchNorm finalize
                 est = take()
-                t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2], amax_in=raw_amax, est_out=est)
+                t4 = bn.finalize(st, raw.shape[0] * raw.shape[1] * raw.shape[2], amax_in=raw_amax, est_out=est, keep=save)
                 raws.append(raw)
                 h, aff, h_amax = raw, (t4[2], t4[3]), est
             out_amax = take()
             if b.ds is not None:
                 rawd, st = ops.conv_fwd(a, b.ds[0].wpk, b.ds[0].cout, 1, b.ds[0].stride, stats=True,
                                         in_amax=a_amax if ops.split_for(1) == 3 else None)
-                td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2])
+                td = b.ds[1].finalize(st, rawd.shape[0] * rawd.shape[1] * rawd.shape[2], keep=save)
                 out = ops.bn_apply(h, aff[0], aff[1], res=rawd, res_affine=(td[2], td[3]), relu=True, mask=use_masks,
                                    amax_out=out_amax)
                 rec["rawd"] = rawd
@@ -407,9 +413,10 @@ class Engine:
         gradient of each ResNet stage has been enqueued (hook for overlapping the gradient all-reduce)."""
         m = self.m
         acc = not m.attach_grads()
-        if self._amax_fwd is not None and saved.get("amax_gen") != self._fwd_gen:
-            raise RuntimeError("backward of a training forward whose operand-scale slots were reused by a later training forward "
-                               "(f16x3 mode keeps one slot table per engine: run backward before the next forward_train)")
+        if saved.get("gen") != self._fwd_gen:
+            raise RuntimeError("backward of a training forward whose BatchNorm statistics rows and operand-scale slots were reused "
+                               "by a later training forward (the engine keeps one set per model: run backward before the next "
+                               "forward that requires grad)")
         with torch.no_grad():
             demb = self._head_bwd(saved["emb"], saved["head"], dlogits, acc)
             dpooled = ops.linear_bwd(saved["pooled"], m.fc1.weight.data, demb, m.fc1.weight.grad, m.fc1.bias.grad,

@@ -521,11 +521,12 @@ def test_split_operands_at_extreme_magnitudes(ops, case):
 
 def test_f16x3_precision_floor_below_the_scale_window(ops):
     """The documented limit of the f16x3 mode (csrc/spk_common.h): operand scales are per TENSOR, so one element 10^7 times
-    the rest pushes the rest below amax * 2^-18, where the second fp16 term leaves the normal range and is lost (measured:
-    the matrix instruction does not keep fp16 subnormals): those elements are carried with 11 significant bits, i.e. an
-    absolute error of at most 2^-12 * amax * 2^-18 = amax * 2^-30 each.  The bf16 modes (fp32's exponent range) have no
-    such floor.  Asserted here: that floor holds (error of every output <= fp32-class relative part + K * amax_x * amax_w
-    * 2^-29), nothing overflows, and the outputs that involve the outlier itself stay fp32-accurate."""
+    the rest pushes the rest below bound * 2^-18, where the second fp16 term leaves the normal range.  The matrix instruction
+    KEEPS fp16 subnormals (tools/probe/run_split_probe.py, profiles/r03_split_probe.log - round 2 documented the opposite from
+    a probe that read freed memory), so those elements degrade gracefully: absolute error <= 2^-25 / sigma <= amax * 2^-39
+    each.  The bf16 modes (fp32's exponent range) have no such floor.  Asserted here: the error of every output <= fp32-class
+    relative part + K * amax_x * amax_w * 2^-29 (the bound round 2 stated; the measured floor is three decades lower),
+    nothing overflows, and the outputs that involve the outlier itself stay fp32-accurate."""
     torch.manual_seed(12)
     B, C, H, Wd = 1, 64, 9, 14
     x = torch.relu(torch.randn(B, C, H, Wd) + 0.3)
