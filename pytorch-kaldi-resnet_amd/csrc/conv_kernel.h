@@ -426,6 +426,10 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     for (int j = 0; j < NT; ++j) {
 #ifdef ABL_NO_BLOAD
                         asm volatile("" : "+v"(bf[s][j]) : "s"(wp));
+#elif defined(ABL_B_HALF)
+                        // diagnostic (wrong numerics): half the weight-fragment bytes through the vector L1, same matrix work
+                        if (s == 0) bf[s][j] = *(const f32x4*)(wp + j * 256);
+                        else { bf[s][j] = bf[0][j]; asm volatile("" : "+v"(bf[s][j])); }
 #else
                         bf[s][j] = *(const f32x4*)(wp + s * term_stride + j * 256);
 #endif

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _make_data(d, n_spk=5, per_spk=12, feat=80):
+def _make_data(d, n_spk=5, per_spk=12, feat=80, frames=208):
     import pytorch_kaldi_resnet_amd  # noqa: F401
     from pytorch_kaldi_resnet_amd import kaldi_io
     rs = np.random.RandomState(1234)
@@ -25,7 +25,7 @@ def _make_data(d, n_spk=5, per_spk=12, feat=80):
         for s in range(n_spk):
             for u in range(per_spk):
                 utt = "spk%02d-utt%02d" % (s, u)
-                T = 208 if u < per_spk - 2 else 232      # decode set: equal-length batches + a different length
+                T = frames if u < per_spk - 2 else frames + 24      # decode set: equal-length batches + a different length
                 mat = (rs.randn(T, feat).astype(np.float32) + spk_mean[s])
                 off = kaldi_io.write_mat(f, mat, key=utt)
                 scp.append("%s %s:%d" % (utt, os.path.join(d, "feats.ark"), off))
@@ -156,3 +156,37 @@ def test_resume_continues_the_uninterrupted_run(tmp_path):
     assert sa["param_groups"][0]["lr"] == pytest.approx(sb["param_groups"][0]["lr"], rel=1e-12)
     for i, ent in sa["state"].items():
         assert torch.equal(ent["momentum_buffer"], sb["state"][i]["momentum_buffer"]), i
+
+
+@pytest.mark.parametrize("reader", ["native", "dataloader"])
+def test_variable_length_training_through_the_entry_point(tmp_path, reader):
+    """BASELINE configs[3] (variable-length batches) through scripts/train_resnet.py: --var-chunk draws ONE chunk length per batch
+    in [--min-chunk-size, --max-chunk-size] (reference scripts/datasets.py:40-43,53-57 draws per sample, which cannot be
+    batched), the step replays one captured hipGraph per distinct length out of a cache that shares one memory pool
+    (engine.GraphedStepCache), and the host cost of a step whose length has been seen before stays below 2 ms.  Both ingest
+    paths: the native reader and Dataset + DataLoader worker processes (the length rides on the index)."""
+    import re
+    d = str(tmp_path)
+    n_spk = _make_data(d, per_spk=14, frames=240)
+    env = dict(os.environ, PYTHONPATH=ROOT, SPK_AUTOTUNE="0")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_resnet.py"), "--gpu", "0", "--workers", "2",
+           "--batch-size", "8", "--print-freq", "1", "--arch", "resnet34", "--input-dim", "80", "--loss-type", "AAM",
+           "--pooling", "mean+std", "--epochs", "3", "--lr", "0.01", "--lr-final", "0.001", "--wd", "5e-4",
+           "--var-chunk", "--min-chunk-size", "200", "--max-chunk-size", "232", "--chunk-quantum", "16",
+           "--train-list", os.path.join(d, "train.scp"), "--cv-list", os.path.join(d, "cv.scp"), "--spk-num", str(n_spk),
+           "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "7", "--log-dir", os.path.join(d, "exp")]
+    if reader == "native":
+        cmd.append("--native-reader")
+    log = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert log.returncode == 0, log.stdout[-3000:] + log.stderr[-3000:]
+    assert "variable-length training: one chunk length per batch in [200, 232] step 16" in log.stdout
+    rep = re.findall(r"epoch (\d+) captured steps: (\d+) \(chunk lengths \[([0-9, ]+)\]\), host enqueue ([0-9.]+) ms/step over (\d+) replays",
+                     log.stdout)
+    assert rep, log.stdout[-2000:]
+    lengths = sorted(int(v) for v in rep[-1][2].split(","))
+    assert set(lengths) <= {200, 216, 232} and len(lengths) >= 2, lengths        # several distinct lengths were trained on
+    assert int(rep[-1][1]) == len(lengths)                                      # one captured step per length, reused across epochs
+    assert float(rep[-1][3]) < 2.0, rep                                         # host enqueue per replayed step
+    assert " * Acc@1 " in log.stdout and os.path.exists(os.path.join(d, "exp", "checkpoint_epoch2.pth.tar"))
+    losses = [float(v) for v in re.findall(r"Loss ([0-9.e+-]+) \(", log.stdout)]
+    assert all(np.isfinite(losses)) and len(losses) > 10
