@@ -102,6 +102,8 @@ def parse():
                     help="also time the loader-inclusive step: seeded ark -> libspkio reader -> pinned ring -> H2D -> graph replay")
     ap.add_argument("--ingest-utts", type=int, default=4096, help="utterances in the synthetic ark of --ingest")
     ap.add_argument("--ingest-threads", type=int, default=8, help="reader threads of --ingest")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the comparison run on the native fp32 matrix instruction (profiled "
+                                                                "runs: keeps its kernels out of the trace)")
     ap.add_argument("--no-f16-window", action="store_true", help="skip the operand-scale window counters (f16x3 mode)")
     a = ap.parse_args()
     if a.config == "c1":
@@ -628,7 +630,7 @@ def main():
     headline = args.arch == "resnet34" and nspk == SPK and var_x is None
     native = None
     if rank == 0 and world == 1 and args.mode == "train" and headline and graphed is not None and ops.SPLIT != 0 \
-            and not args.no_roofline:
+            and not args.no_roofline and not args.no_fp32_leg:
         # the same step on the native fp32 matrix instruction, timed the same way, for comparison (N = 1 only)
         from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
         keep = ops.SPLIT

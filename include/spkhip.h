@@ -206,7 +206,8 @@ int spk_affine_estimate(const float* scale, const float* shift, int C, const uns
 /* ---- statistics pooling (StatsPooling, scripts/model.py:435-457; mode 0 = 'mean', 1 = 'mean+std') -------- */
 int spk_stats_pool_fwd(const float* x /*[B][H][W][C]*/, float* out /*[B][C*H*(1+mode)]*/, int B, int H, int W, int C,
                        int mode, void* stream);
-int spk_stats_pool_bwd(const float* x, const float* gout, float* dx, int B, int H, int W, int C, int mode, void* stream);
+int spk_stats_pool_bwd(const float* x, const float* gout, float* dx, int B, int H, int W, int C, int mode,
+                       unsigned* amax_out /* optional: atomicMax of the float bits of |dx| */, void* stream);
 
 /* ---- GEMM (fc1 = nn.Linear(5120,256) scripts/model.py:357; cosine F.linear :485; their gradients) ------ */
 /* C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]) (+ C[m][n]).  64x64 tiles on the fp32 matrix

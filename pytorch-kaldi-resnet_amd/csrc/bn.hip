@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ 
     if (nbt && blockIdx.x == 0 && tid == 0) *nbt += 1;
 }
 
+// (two stages from 256 partial rows on: the single-stage finalize walks nblk / 8 rows serially per channel block - measured
+//  42-49 us at 1024 rows against 9 + 13 us for the fold + the 256-row finalize)
 extern "C" size_t spk_bn_finalize_workspace(int nblk, int C) {
-    return nblk > 4 * BN_STAGE_ROWS ? (size_t)BN_STAGE_ROWS * C * 2 * sizeof(double) : 0;
+    return nblk > BN_STAGE_ROWS ? (size_t)BN_STAGE_ROWS * C * 2 * sizeof(double) : 0;
 }
 
 extern "C" int spk_bn_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta,

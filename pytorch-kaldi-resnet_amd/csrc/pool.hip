@@ -38,28 +38,37 @@ __global__ __launch_bounds__(256) void stats_pool_fwd_kernel(const float* __rest
 // dx = gvar * 2(x - mean)/(W-1) + gsqrt / (2 sqrt(mean)) / W      (IEEE semantics kept: mean == 0 gives inf/nan
 // exactly like torch's sqrt backward)
 __global__ __launch_bounds__(256) void stats_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
-                                                             float* __restrict__ dx, int B, int H, int W, int C, int mode) {
+                                                             float* __restrict__ dx, int B, int H, int W, int C, int mode,
+                                                             unsigned* __restrict__ amax_out) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)B * H * C;
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const long long bh = idx / C;
-    const int h = (int)(bh % H);
-    const int b = (int)(bh / H);
-    const float* p = x + (size_t)bh * W * C + c;
-    float* q = dx + (size_t)bh * W * C + c;
-    if (mode == 0) {
-        const float g = gout[(size_t)b * C * H + (size_t)c * H + h] / (float)W;
-        for (int w = 0; w < W; ++w) q[(size_t)w * C] = g;
-        return;
+    float mx = 0.f;                      // absmax of what this thread stores (the operand scale of the f16x3 consumers of dx)
+    if (idx < total) {
+        const int c = (int)(idx % C);
+        const long long bh = idx / C;
+        const int h = (int)(bh % H);
+        const int b = (int)(bh / H);
+        const float* p = x + (size_t)bh * W * C + c;
+        float* q = dx + (size_t)bh * W * C + c;
+        if (mode == 0) {
+            const float g = gout[(size_t)b * C * H + (size_t)c * H + h] / (float)W;
+            for (int w = 0; w < W; ++w) q[(size_t)w * C] = g;
+            mx = fabsf(g);
+        } else {
+            float s = 0.f;
+            for (int w = 0; w < W; ++w) s += p[(size_t)w * C];
+            const float mean = s / (float)W;
+            const float* g = gout + (size_t)b * C * 2 * H + (size_t)c * 2 * H;
+            const float gv = g[h] * (2.f / (float)(W - 1));
+            const float gm = g[H + h] / (2.f * sqrtf(mean)) / (float)W;
+            for (int w = 0; w < W; ++w) {
+                const float v = fmaf(gv, p[(size_t)w * C] - mean, gm);
+                q[(size_t)w * C] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        }
     }
-    float s = 0.f;
-    for (int w = 0; w < W; ++w) s += p[(size_t)w * C];
-    const float mean = s / (float)W;
-    const float* g = gout + (size_t)b * C * 2 * H + (size_t)c * 2 * H;
-    const float gv = g[h] * (2.f / (float)(W - 1));
-    const float gm = g[H + h] / (2.f * sqrtf(mean)) / (float)W;
-    for (int w = 0; w < W; ++w) q[(size_t)w * C] = fmaf(gv, p[(size_t)w * C] - mean, gm);
+    if (amax_out) spk_wave_amax_commit(mx, amax_out);     // every lane of the wave takes part (no early return above)
 }
 
 extern "C" int spk_stats_pool_fwd(const float* x, float* out, int B, int H, int W, int C, int mode, void* stream) {
@@ -74,13 +83,13 @@ extern "C" int spk_stats_pool_fwd(const float* x, float* out, int B, int H, int 
 }
 
 extern "C" int spk_stats_pool_bwd(const float* x, const float* gout, float* dx, int B, int H, int W, int C, int mode,
-                                  void* stream) {
+                                  unsigned* amax_out, void* stream) {
     SPK_REQUIRE(x && gout && dx, "spk_stats_pool_bwd: null pointer");
     SPK_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "spk_stats_pool_bwd: empty input");
     SPK_REQUIRE(mode == 0 || mode == 1, "spk_stats_pool_bwd: mode=%d", mode);
     const long long total = (long long)B * H * C;
     hipLaunchKernelGGL(stats_pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, gout,
-                       dx, B, H, W, C, mode);
+                       dx, B, H, W, C, mode, amax_out);
     SPK_LAUNCH_CHECK("spk_stats_pool_bwd");
     return 0;
 }

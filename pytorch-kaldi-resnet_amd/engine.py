@@ -141,9 +141,10 @@ class Engine:
         # pair tensor, and the data gradient (in-wave pipelined kernel) and the weight gradient stage it by plain copy
         # (None = by operand mode: 32 in the f16x3 mode with pair tensors, no limit otherwise; SPK_FUSE_APPLY_MAXC overrides)
         self._fuse_apply_max_c = int(os.environ["SPK_FUSE_APPLY_MAXC"]) if "SPK_FUSE_APPLY_MAXC" in os.environ else None
-        # 1x1 convolutions (Bottleneck blocks) keep the fusion at every width: they are HBM-bound, the fusion saves a tensor pass
-        # (ResNet-101, measured: 19.2 ms fused against 12.1 + ~10 ms for the separate pass + plain data gradient)
-        self.fuse_apply_1x1 = os.environ.get("SPK_FUSE_APPLY_1X1", "1") == "1"
+        # opt-in: 1x1 convolutions (Bottleneck blocks) keep the fusion at every width.  They are HBM-bound and the fusion saves a
+        # tensor pass, but the fused 1x1 kernel is VALU-bound: ResNet-101 with one chunk length per step in [200, 400], same box:
+        # 105.7-106.2 ms without it, 110.6-110.9 ms with it, 112.3 ms with every convolution fused (profiles/r03_c4_policy.log)
+        self.fuse_apply_1x1 = os.environ.get("SPK_FUSE_APPLY_1X1", "0") == "1"
         # gradients wrt raw conv outputs travel as f16 pair tensors (include/spkhip.h) in the f16x3 mode
         self.pair_draw = os.environ.get("SPK_PAIR_DRAW", "1") == "1"
         # diagnostics (tests / bench, never the timed path): when a [4] int64 device tensor, every tensor that an f16x3
@@ -424,17 +425,17 @@ class Engine:
             demb = self._head_bwd(saved["emb"], saved["head"], dlogits, acc)
             dpooled = ops.linear_bwd(saved["pooled"], m.fc1.weight.data, demb, m.fc1.weight.grad, m.fc1.bias.grad,
                                      accumulate=acc)
-            d = ops.stats_pool_bwd(saved["feat"], dpooled, self.pool_mode)
             # f16x3 operand mode of the backward kernels: every gradient tensor that feeds a matrix-core stage travels with
             # a slot holding the float bits of its absmax (atomicMax'ed by the kernel that writes it); the consumer derives
             # its power-of-two operand scale from it.  Slots are taken in a fixed order from a table zeroed once per step.
             amx = None
             if ops.split_for(3, True) == 3:
                 if self._amax_pool is None:
-                    self._amax_pool = ops.AmaxPool(d.device)
+                    self._amax_pool = ops.AmaxPool(dpooled.device)
                 amx = self._amax_pool
                 amx.reset()
-            d_amax = ops.absmax_into(d, amx.take()) if amx else None
+            d_amax = amx.take() if amx else None
+            d = ops.stats_pool_bwd(saved["feat"], dpooled, self.pool_mode, amax_out=d_amax)
             if on_stage_done:
                 on_stage_done("head")
             nblk = len(self.blocks)

@@ -47,7 +47,7 @@ _SIGS = {
     "spk_f16_window_count": [_P, _P, _P, _L, _I, _P, _I, _P, _P],
     "spk_affine_estimate": [_P, _P, _I, _P, _P, _P],
     "spk_stats_pool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "spk_stats_pool_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "spk_gemm_f32": [_P] * 4 + [_I] * 3 + [_L] * 5 + [_F, _I, _P, _P],
     "spk_gemm_splitk": [_I, _I, _I],
     "spk_colsum": [_P, _P, _I, _I, _I, _P],

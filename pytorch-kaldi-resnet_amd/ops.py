@@ -704,10 +704,11 @@ def stats_pool_fwd(x, mode):
     return out
 
 
-def stats_pool_bwd(x, gout, mode):
+def stats_pool_bwd(x, gout, mode, amax_out=None):
+    """amax_out: slot the launch atomically maxes |dx| into (float bits): the operand scale of dx's f16x3 consumers"""
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    call("spk_stats_pool_bwd", ptr(x), ptr(gout), ptr(dx), B, H, W, C, mode, stream())
+    call("spk_stats_pool_bwd", ptr(x), ptr(gout), ptr(dx), B, H, W, C, mode, ptr(amax_out), stream())
     return dx
 
 

@@ -626,12 +626,17 @@ def test_stats_pool_golden_and_random(ops, gold_dir):
         ref = g["pool_%s_y" % name].reshape(2, -1)
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-6, atol=1e-7)
         gy = torch.from_numpy(g["pool_%s_gy" % name].reshape(2, -1)).cuda()
-        dx = ops.stats_pool_bwd(nhwc(x), gy, mode)
+        slot = torch.zeros(1, device="cuda", dtype=torch.int32)
+        dx = ops.stats_pool_bwd(nhwc(x), gy, mode, amax_out=slot)
         np.testing.assert_allclose(nchw(dx).numpy(), g["pool_%s_gx" % name], rtol=1e-5, atol=1e-7)
+        assert float(slot.cpu().view(torch.float32)[0]) == float(dx.abs().max())      # absmax hand-off of the f16x3 mode
     xr = rnd(31, 3, 256, 10, 38, scale=0.5, shift=0.6)
     yo = O.stats_pool(xr, "mean+std").flatten(1)
     y = ops.stats_pool_fwd(nhwc(xr), 1)
     assert relerr(y.cpu(), yo) < 2e-6
+    slot = torch.zeros(1, device="cuda", dtype=torch.int32)              # a grid that does not fill its last wave
+    dx = ops.stats_pool_bwd(nhwc(xr), rnd(32, 3, 256 * 10 * 2).cuda(), 1, amax_out=slot)
+    assert float(slot.cpu().view(torch.float32)[0]) == float(dx.abs().max())
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 5120), (6, 11, 256), (256, 1211, 256), (37, 70, 129)])
