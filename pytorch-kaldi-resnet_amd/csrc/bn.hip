@@ -213,6 +213,10 @@ extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 // ---- apply: out = [relu]( raw*scale + shift [+ res | + res*rscale + rshift] ) -----------------------
+#ifndef BN_STREAM_U
+#define BN_STREAM_U 1      // 16-byte groups in flight per thread and input stream in the streaming kernels below (2 and 4 measured:
+                           // 54.45 / 54.50 ms per step against 54.34 - these passes already run at the achievable HBM rate)
+#endif
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -220,33 +224,50 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int C, int relu, unsigned* __restrict__ amax_out) {
     const int cmask = C - 1;
     float mx = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i * 4) & cmask);
-        f32x4 v = *(const f32x4*)(raw + i * 4);
-        v = v * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
-        if (res) {
-            f32x4 rv = *(const f32x4*)(res + i * 4);
-            if (rscale) rv = rv * *(const f32x4*)(rscale + c) + *(const f32x4*)(rshift + c);
-            v += rv;
+    constexpr int U = BN_STREAM_U;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nquads; i0 += stride * U) {
+        // U independent groups per thread: all their loads are issued before the first use (a group past the end re-reads
+        // group i0 and is dropped) - more bytes in flight per CU on these HBM-bound streams
+        f32x4 rv[U], sv[U];
+        long long idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + stride * u;
+            idx[u] = i < nquads ? i : i0;
+            rv[u] = *(const f32x4*)(raw + idx[u] * 4);
+            if (res) sv[u] = *(const f32x4*)(res + idx[u] * 4);
         }
-        if (relu) {
-            v[0] = fmaxf(v[0], 0.f);
-            v[1] = fmaxf(v[1], 0.f);
-            v[2] = fmaxf(v[2], 0.f);
-            v[3] = fmaxf(v[3], 0.f);
-        }
-        *(f32x4*)(out + i * 4) = v;
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        if (mask_out) {
-            // sign mask of the output, one bit per value, 32 channels per word: the backward pass reads these bits instead
-            // of the whole activated tensor.  Eight consecutive lanes hold the 32 channels of one word (C % 32 == 0, the
-            // grid stride is a multiple of the wave size: the eight lanes are always active together).
-            unsigned bits = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
-            bits <<= 4 * (threadIdx.x & 7);
-            bits |= __shfl_xor(bits, 1, 64);
-            bits |= __shfl_xor(bits, 2, 64);
-            bits |= __shfl_xor(bits, 4, 64);
-            if ((threadIdx.x & 7) == 0) mask_out[i >> 3] = bits;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + stride * u;
+            if (i >= nquads) continue;
+            const int c = (int)((i * 4) & cmask);
+            f32x4 v = rv[u] * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+            if (res) {
+                f32x4 r = sv[u];
+                if (rscale) r = r * *(const f32x4*)(rscale + c) + *(const f32x4*)(rshift + c);
+                v += r;
+            }
+            if (relu) {
+                v[0] = fmaxf(v[0], 0.f);
+                v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f);
+                v[3] = fmaxf(v[3], 0.f);
+            }
+            *(f32x4*)(out + i * 4) = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if (mask_out) {
+                // sign mask of the output, one bit per value, 32 channels per word: the backward pass reads these bits instead
+                // of the whole activated tensor.  Eight consecutive lanes hold the 32 channels of one word (C % 32 == 0, the
+                // grid stride is a multiple of the wave size: the eight lanes are always active together).
+                unsigned bits = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                bits <<= 4 * (threadIdx.x & 7);
+                bits |= __shfl_xor(bits, 1, 64);
+                bits |= __shfl_xor(bits, 2, 64);
+                bits |= __shfl_xor(bits, 4, 64);
+                if ((threadIdx.x & 7) == 0) mask_out[i >> 3] = bits;
+            }
         }
     }
     if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(out): the operand scale of its f16x3 consumers
@@ -438,23 +459,55 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int cmask = C - 1;
     float mx = 0.f;
     const float sig = pair_scale ? spk_sigma_from_amax_bits(*pair_scale) : 1.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (long long)gridDim.x * 256) {
-        const int c = (int)((i * 4) & cmask);
-        const long long off = i * 4;
-        const f32x4 rv = *(const f32x4*)(raw + off);
-        f32x4 d = *(const f32x4*)(dy + off);
-        d = bn_mask(d, mode, act, raw, rv, *(const f32x4*)(scale + c), *(const f32x4*)(shift + c), off, C);
-        const f32x4 xh = (rv - *(const f32x4*)(mean + c)) * *(const f32x4*)(invstd + c);
-        const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
-        const f32x4 o = k1 * (d - m1 - xh * m2);
-        if (dz_out) *(f32x4*)(dz_out + off) = d;
-        if (pair_scale) {      // f16 pair tensor: converted here once, staged by plain copy in the data and weight gradients
-            uint2 t0, t1;
-            split2h(o, sig, t0, t1);
-            *(f32x4*)(draw + off) = spk_pair_pack(t0, t1);
-        } else
-            *(f32x4*)(draw + off) = o;
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    constexpr int U = BN_STREAM_U;
+    const long long stride = (long long)gridDim.x * 256;
+    const int lg = 31 - __builtin_clz((unsigned)C);          // C is a power of two
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nquads; i0 += stride * U) {
+        f32x4 rvv[U], dv[U], av[U];
+        unsigned mw[U];
+        long long idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {          // all loads of the U groups first (a group past the end re-reads group i0)
+            const long long i = i0 + stride * u;
+            idx[u] = i < nquads ? i : i0;
+            const long long off = idx[u] * 4;
+            rvv[u] = *(const f32x4*)(raw + off);
+            dv[u] = *(const f32x4*)(dy + off);
+            if (mode == MASK_BITS) mw[u] = ((const unsigned*)act)[(off >> lg) * (C >> 5) + ((int)(off & cmask) >> 5)];
+            else if (mode == MASK_ACT) av[u] = *(const f32x4*)(act + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + stride * u;
+            if (i >= nquads) continue;
+            const int c = (int)((i * 4) & cmask);
+            const long long off = i * 4;
+            const f32x4 rv = rvv[u];
+            f32x4 d = dv[u];
+            if (mode == MASK_BITS) {
+                const unsigned bits = mw[u] >> (c & 31);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = ((bits >> k) & 1u) ? d[k] : 0.f;
+            } else if (mode == MASK_ACT) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = av[u][k] > 0.f ? d[k] : 0.f;
+            } else if (mode == MASK_RAW) {
+                const f32x4 z = rv * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = z[k] > 0.f ? d[k] : 0.f;
+            }
+            const f32x4 xh = (rv - *(const f32x4*)(mean + c)) * *(const f32x4*)(invstd + c);
+            const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
+            const f32x4 o = k1 * (d - m1 - xh * m2);
+            if (dz_out) *(f32x4*)(dz_out + off) = d;
+            if (pair_scale) {      // f16 pair tensor: converted here once, staged by plain copy in the data and weight gradients
+                uint2 t0, t1;
+                split2h(o, sig, t0, t1);
+                *(f32x4*)(draw + off) = spk_pair_pack(t0, t1);
+            } else
+                *(f32x4*)(draw + off) = o;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        }
     }
     if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(draw): the operand scale of its f16x3 consumers
 }

@@ -22,6 +22,9 @@ ap.add_argument("--trials", type=int, default=100000)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workers", type=int, default=8)
 ap.add_argument("--out-format", default="text")
+ap.add_argument("--oracle-subset", type=int, default=2048,
+                help="the CPU oracle (the checker) extracts the first N utterances from the same checkpoint: max 1 - cos against the "
+                     "HIP embeddings and the EER of both on 20 k seeded trials inside the subset (SURVEY.md section 8d, C5); 0 = skip")
 a = ap.parse_args()
 py = sys.executable
 sc = os.path.join(ROOT, "scripts")
@@ -73,4 +76,43 @@ res["eer"] = eer.strip().splitlines()[-1]
 _, eer_h = run([py, os.path.join(sc, "compute_eer.py"), os.path.join(a.dir, "scores_host"), os.path.join(a.dir, "trials")])
 res["eer_host_scores"] = eer_h.strip().splitlines()[-1]
 res["trials"] = len(s_d)
+if a.oracle_subset:
+    # the checker: CPU oracle on a subset, same checkpoint (oracle/ is test infrastructure: only compared against here)
+    from oracle import spk_oracle as O  # noqa: E402
+    from pytorch_kaldi_resnet_amd import kaldi_io, scoring  # noqa: E402
+    # spread over speakers: every (len // N)-th line
+    alll = [l.split() for l in open(os.path.join(a.dir, "all.scp"))]
+    step = max(1, len(alll) // a.oracle_subset)
+    sub = alll[::step][:a.oracle_subset]
+    st = {k: v.clone() for k, v in torch.load(ck, map_location="cpu", weights_only=True)["state_dict"].items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t = time.time()
+    o_emb = {}
+    with torch.no_grad():
+        for i in range(0, len(sub), 32):
+            xs = torch.from_numpy(np.stack([np.ascontiguousarray(kaldi_io.read_mat(rx).T) for _, rx in sub[i:i + 32]]))
+            e = O.embed(st, xs, "mean+std", "resnet34", train=False).numpy().astype(np.float64)
+            for (utt, _), v in zip(sub[i:i + 32], e):
+                o_emb[utt] = v
+    res["oracle_subset_utts"], res["oracle_extract_s"] = len(sub), round(time.time() - t, 2)
+    hip_emb = scoring.read_embeddings(iv)
+    worst = 0.0
+    for utt, v in o_emb.items():
+        h = np.asarray(hip_emb[utt], dtype=np.float64)
+        worst = max(worst, 1.0 - float(h @ v / (np.linalg.norm(h) * np.linalg.norm(v))))
+    res["oracle_subset_max_1_minus_cos"] = worst
+    rs = np.random.RandomState(77)
+    names = [u for u, _ in sub]
+    tr = os.path.join(a.dir, "trials_subset")
+    with open(tr, "w") as f:
+        for _ in range(20000):
+            i, j = rs.randint(0, len(names), 2)
+            if i != j:
+                f.write("%s %s %s\n" % (names[i], names[j], "target" if names[i][:7] == names[j][:7] else "nontarget"))
+    h_sub = {u: np.asarray(hip_emb[u], dtype=np.float64) for u in names}
+    for tag, emb in (("hip", h_sub), ("oracle", o_emb)):
+        mean = np.mean(np.stack([emb[u] for u in names]).astype(np.float32), axis=0)
+        sc_, lab_ = scoring.cosine_score(emb, emb, tr, mean)
+        res["subset_eer_" + tag] = round(float(scoring.compute_eer(sc_, lab_)), 5)
+        res["subset_targets"] = int(lab_.sum())
 print(json.dumps(res))
