@@ -153,11 +153,22 @@ def ws_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
     return _ws_tile(*key)
 
 
+# experiment knob (tile sweeps inside the training step): SPK_FUSED_TILE="OH,OW,Cout:TH,TW,MT,NT" overrides the tile of the fused
+# BatchNorm-backward data gradient of that shape
+_FUSED_TILE_OVERRIDE = None
+if _os.environ.get("SPK_FUSED_TILE"):
+    _k, _v = _os.environ["SPK_FUSED_TILE"].split(":")
+    _oh, _ow, _co = (int(x) for x in _k.split(","))
+    _FUSED_TILE_OVERRIDE = ((_oh, _ow, 1, 3, 3, 9, _co), tuple(int(x) for x in _v.split(",")))
+
+
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     """mode 1 = data gradient with the BatchNorm backward fused into its input staging (heavier staging: it may prefer
     wider channel tiles); table keys carry the mode as an 8th element and fall back to the plain entry.  split != 0
     (bf16-split operands) consults its own table first."""
     key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
+    if mode and _FUSED_TILE_OVERRIDE and key == _FUSED_TILE_OVERRIDE[0]:
+        return _FUSED_TILE_OVERRIDE[1]
     if split:
         if mode and key + (mode,) in FORCE_CONV_SPLIT:
             return FORCE_CONV_SPLIT[key + (mode,)]
