@@ -2,18 +2,18 @@
 
 What is compared, and why these tolerances:
   * eval-mode embeddings / logits and train-mode logits / loss (forward only): well conditioned; the BASELINE
-    bar is cosine >= 1 - 1e-4, we assert 1e-6 on cosine and 2e-5 scale-relative on values.
-  * gradients: the trunk gradient of this network is ill-conditioned in fp32 - the oracle's OWN fp32 gradient
-    differs from its fp64 gradient by 5e-4 .. 3e-2 norm-relative depending on the batch (cancellation in the
-    BatchNorm backward; see DESIGN.md "gradient conditioning"), and a forward difference of 1e-5 (which is what
-    two correct fp32 implementations with different summation orders show after 30 layers) flips the ReLU mask of
-    the few activations with |z| < 1e-5, each flip moving one channel's bias gradient by a whole element.
-    Measured on MI355X: HIP-vs-fp64 1.2e-2 where oracle-fp32-vs-fp64 is 5.5e-4 (r34_softmax_mean_f40), 3.0e-2
-    vs 2.7e-2 (r101).  Budget asserted: 3x the fp32 oracle's own error + 2e-2 norm-relative on the whole
-    gradient, 5e-4 on the well-conditioned head matrices, 2e-2 on every parameter's gradient norm vs the
-    reference's recorded norms.
-  * loss curve over 5 SGD steps (lr 2e-5): step 0 within 1e-4, later steps within a budget that grows with the
-    measured chaotic amplification of the reference itself (see test_sgd_loss_curve).
+    bar is cosine >= 1 - 1e-4, asserted: 1e-6 on cosine, 2e-5 scale-relative on values, 1e-4 on the train-mode loss at
+    step 0 - 2e-4 for ResNet-101 at batch 2, whose train-mode BatchNorm over two utterances amplifies
+    forward rounding (measured 1.1e-4).
+  * gradients (test_backward_parity): against the fp64 gradient of the SAME piecewise-linear function - the oracle forward
+    replayed with the ReLU masks the HIP forward chose (oracle/masked.py) - within 3x the CPU fp32 path's own error under
+    the same yardstick (4x for the heads with a BatchNorm1d over 3-4 embeddings), no additive slack; the masks themselves
+    within the CPU fp32 path's (Poisson) disagreement with the fp64 forward; the free-running comparison keeps a budget
+    derived from the flip count; every parameter's gradient norm against the norms recorded from the reference.
+  * loss curve over 5 SGD steps: step 0 within 1e-4, later steps within a budget derived from the reference's measured
+    distance to ITSELF under 1-ulp input noise and fp64 arithmetic (loss_curve_tol, tests/golden/ref_sensitivity.json).
+  * the same comparisons at the size of the headline (batch 256, 300 frames, 1211 speakers) between the operand modes:
+    tests/test_fullsize_gpu.py.
 """
 import json
 import os
@@ -104,7 +104,8 @@ def test_forward_parity(P, gold_dir, name):
     loss = torch.nn.functional.cross_entropy(logits, yg)
     # train-mode BN over a batch of 2-4 utterances amplifies rounding differences more than eval mode
     assert srel(logits.detach().cpu().numpy(), g["logits_train"]) < 2e-4
-    assert abs(float(loss) - float(g["loss_train"])) < 5e-4    # r101 at batch 2: 1.1e-4 measured
+    # 1e-4 at step 0; ResNet-101 at batch 2 (train-mode BatchNorm over two utterances): 1.1e-4 measured
+    assert abs(float(loss) - float(g["loss_train"])) < (2e-4 if name == "r101_aam" else 1e-4), name
     # BN running statistics after exactly one training forward
     sd = m.state_dict()
     for key in g.files:
@@ -217,7 +218,7 @@ def test_backward_parity(P, gold_dir, name):
     for i, n in enumerate(names):
         ref = float(g["grad_norm"][i])
         assert abs(float(hip[n].norm()) - ref) <= tol * ref + 1e-5, n
-    assert abs(loss_hip - float(g["loss_train"])) < 5e-4
+    assert abs(loss_hip - float(g["loss_train"])) < (2e-4 if name == "r101_aam" else 1e-4), name
 
 
 def test_fused_step_equals_autograd_path(P, gold_dir):
