@@ -533,9 +533,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     const long long nq = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) {
         const f32x4 v = *(const f32x4*)(x + i * 4);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        mx = fmaxf(fmaxf(mx, fmaxf(spk_finite_abs(v[0]), spk_finite_abs(v[1]))), fmaxf(spk_finite_abs(v[2]), spk_finite_abs(v[3])));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[nq * 4 + threadIdx.x]));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, spk_finite_abs(x[nq * 4 + threadIdx.x]));
     spk_wave_amax_commit(mx, slot);
 }
 

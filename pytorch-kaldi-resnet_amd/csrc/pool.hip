@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void stats_pool_bwd_kernel(const float* __rest
         if (mode == 0) {
             const float g = gout[(size_t)b * C * H + (size_t)c * H + h] / (float)W;
             for (int w = 0; w < W; ++w) q[(size_t)w * C] = g;
-            mx = fabsf(g);
+            mx = spk_finite_abs(g);
         } else {
             float s = 0.f;
             for (int w = 0; w < W; ++w) s += p[(size_t)w * C];
@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void stats_pool_bwd_kernel(const float* __rest
             for (int w = 0; w < W; ++w) {
                 const float v = fmaf(gv, p[(size_t)w * C] - mean, gm);
                 q[(size_t)w * C] = v;
-                mx = fmaxf(mx, fabsf(v));
+                // sqrt'(0) = inf: a row whose mean over time is exactly 0 (a dead post-ReLU channel row) gets inf / NaN here, as in
+                // the reference (torch.sqrt backward); the ReLU mask of that row is 0, so the select in the BatchNorm backward
+                // drops those values (threshold_backward semantics) - they must not poison the operand scale of everything else
+                mx = fmaxf(mx, spk_finite_abs(v));
             }
         }
     }

@@ -150,6 +150,7 @@ class Engine:
         # diagnostics (tests / bench, never the timed path): when a [4] int64 device tensor, every tensor that an f16x3
         # matrix-core kernel stages is also run through spk_f16_window_count under the scale slot its consumer uses
         self.window_counts = None
+        self.bound_log = None          # diagnostics: when a list, (Cout, k, bound slot, true-absmax slot) of every BatchNorm-backward scale
 
     # ---- helpers ---------------------------------------------------------------------------------------
     @property
@@ -529,6 +530,8 @@ class Engine:
                     dz = dzb
                 draw_slot = est if pairs else draw_amax
                 self._count(draw, draw_slot, pairs=pairs)
+                if self.bound_log is not None and est is not None:
+                    self.bound_log.append((c.cout, c.k, est, draw_amax))
             else:
                 lazy_dz = False
                 est = take() if pairs else None
@@ -549,6 +552,8 @@ class Engine:
                                            draw_out=g, accumulate=acc, partial=g_part, amax_out=draw_amax, pair=pair)
                 draw_slot = est if pairs else draw_amax
                 self._count(draw, draw_slot, pairs=pairs)
+                if self.bound_log is not None and est is not None:
+                    self.bound_log.append((c.cout, c.k, est, draw_amax))
                 if add_dz and dz is None and rec.get("mask") is not None:
                     res = ops.conv_dgrad(draw, c.wpk_t, c.cin, c.k, c.stride, hw, add=dout, add_mask=rec["mask"], bn_bwd=bnb,
                                          in_amax=draw_slot if f16 else None, out_amax=res_amax, in_presplit=pairs)

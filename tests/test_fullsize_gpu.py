@@ -176,3 +176,62 @@ def test_operand_scale_slots_survive_an_eval_forward_between_forward_and_backwar
     m(xg, yg)                                   # a second training forward reuses the rows and slots of the first
     with pytest.raises(RuntimeError, match="reused"):
         torch.nn.functional.cross_entropy(logits, yg).backward()
+
+
+def test_dead_channel_rows_at_the_pooling_input_do_not_poison_the_operand_scales(P, gold_dir):
+    """Found on a TRAINED checkpoint (tools/window_on_checkpoint.py): a channel row of the last block's output that is zero over
+    the whole utterance has mean 0, the pooling layer's sqrt'(0) puts inf / NaN into the gradient there (the reference does the
+    same: torch.sqrt backward, scripts/model.py:453), and the ReLU mask select drops them one step later.  In f16x3 the absmax
+    hand-off of that gradient used to become inf -> operand scale 1 for the whole tensor -> gradients of 1e-6 carried as fp16
+    subnormals: 40 % error in layer 4.  Here: three dead output channels in every layer-4 block; the backward pass in f16x3
+    must stay finite and agree with the exact split mode on the same forward like the native fp32 instruction does."""
+    from pytorch_kaldi_resnet_amd import ops
+    from pytorch_kaldi_resnet_amd.model import NeuralSpeakerModel
+    meta = json.load(open(os.path.join(gold_dir, "c1_r34_aam.json")))
+    npst = W.make_state(meta["seed"], meta["spk_num"], meta["feat_dim"], meta["pooling"], meta["loss"], meta["arch"])
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in npst.items()}
+    dead = [5, 77, 200]
+    for blk in range(3):                       # relu(bn2(.) + shortcut) == 0 needs the whole residual chain of the channel dead
+        for key in ("res.layer4.%d.bn2" % blk,) + (("res.layer4.0.downsample.1",) if blk == 0 else ()):
+            sd[key + ".weight"][dead] = 0.0
+            sd[key + ".bias"][dead] = -1.0
+    m = NeuralSpeakerModel(meta["spk_num"], meta["feat_dim"], meta["pooling"], meta["loss"], 0.2, 30, arch=meta["arch"])
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    eng = m.engine()
+    x, y = W.make_input(meta["seed"] + 1, meta["batch"], meta["feat_dim"], meta["frames"], meta["spk_num"])
+    xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    buf0 = [b.clone() for b in m.buffers()]
+    old, old_bwd = ops.SPLIT, ops.SPLIT_BWD
+    grads = {}
+    try:
+        for bwd in ("bf16x6", "f16x3", "f32"):
+            ops.SPLIT, ops.SPLIT_BWD = ops.MFMA_MODES["bf16x6"], ops.MFMA_MODES[bwd]
+            eng.dirty = True
+            for b, b0 in zip(m.buffers(), buf0):
+                b.copy_(b0)
+            for p in m.parameters():
+                p.grad = None
+            if bwd == "f16x3":
+                eng.window_counts = torch.zeros(4, device="cuda", dtype=torch.int64)
+            loss, _, _ = eng.loss_and_grad(xg, yg)
+            torch.cuda.synchronize()
+            if bwd == "f16x3":
+                counts, eng.window_counts = eng.window_counts.tolist(), None
+            grads[bwd] = m.flat_grads().clone()
+            assert bool(torch.isfinite(grads[bwd]).all()) and np.isfinite(float(loss)), bwd
+    finally:
+        ops.SPLIT, ops.SPLIT_BWD = old, old_bwd
+    assert counts[1] == 0
+    ref = grads["bf16x6"].double()
+    e_h = float((grads["f16x3"].double() - ref).norm() / ref.norm())
+    e_f = float((grads["f32"].double() - ref).norm() / ref.norm())
+    print("dead pooling rows: same-forward backward vs exact split: f16x3 %.2e, native fp32 instruction %.2e" % (e_h, e_f))
+    assert e_h <= 2.0 * e_f + 1e-6, (e_h, e_f)
+    # the dead channels really produce non-finite pooling gradients (the case under test is exercised)
+    with torch.no_grad():
+        _, saved = eng.forward_train(xg, yg)
+        feat = saved["feat"]
+        assert float(feat[..., dead].abs().max()) == 0.0
+        d = ops.stats_pool_bwd(feat, torch.ones(feat.shape[0], feat.shape[3] * feat.shape[1] * 2, device="cuda"), 1)
+        assert not bool(torch.isfinite(d).all())

@@ -637,6 +637,21 @@ def test_stats_pool_golden_and_random(ops, gold_dir):
     slot = torch.zeros(1, device="cuda", dtype=torch.int32)              # a grid that does not fill its last wave
     dx = ops.stats_pool_bwd(nhwc(xr), rnd(32, 3, 256 * 10 * 2).cuda(), 1, amax_out=slot)
     assert float(slot.cpu().view(torch.float32)[0]) == float(dx.abs().max())
+    # a dead row (all zeros over time: mean 0): sqrt'(0) gives inf / NaN there exactly as torch.sqrt's backward does in the
+    # reference (scripts/model.py:453: the ReLU mask select drops them one step later); the absmax hand-off leaves them out
+    xz = xr.clone()
+    xz[1, 7, 3, :] = 0.0
+    xz[2, 100, 0, :] = 0.0
+    gy = rnd(33, 3, 256 * 10 * 2)
+    gy[2, 100 * 20 + 10 + 0] = 0.0                  # 0 / 0 -> NaN in that row, g / 0 -> inf in the other
+    xt = xz.clone().requires_grad_(True)
+    gref, = torch.autograd.grad(O.stats_pool(xt, "mean+std").flatten(1), [xt], grad_outputs=gy)
+    slot = torch.zeros(1, device="cuda", dtype=torch.int32)
+    dx = nchw(ops.stats_pool_bwd(nhwc(xz), gy.cuda(), 1, amax_out=slot))
+    bad = ~torch.isfinite(gref)
+    assert int(bad.sum()) == 2 * 38 and torch.equal(bad, ~torch.isfinite(dx))
+    np.testing.assert_allclose(dx[~bad].numpy(), gref[~bad].numpy(), rtol=2e-5, atol=1e-7)
+    assert float(slot.cpu().view(torch.float32)[0]) == float(dx[~bad].abs().max())
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 5120), (6, 11, 256), (256, 1211, 256), (37, 70, 129)])
