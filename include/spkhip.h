@@ -25,6 +25,10 @@ extern "C" {
 
 int spk_version(void);
 const char* spk_last_error(void);
+/* bit 0: the library was built with SPK_EXPERIMENTAL=1 and contains the kernel forms that were measured and did not pay
+ * (SPK_CONV_WS of spk_conv_mfma / spk_conv_wgrad, SPK_CONV_PIPE of spk_conv_wgrad, SPK_CONV_PIPE + SPK_IN_BNBWD of spk_conv_mfma);
+ * without it those flag combinations are argument errors */
+int spk_build_flags(void);
 
 /* flags for the fused input transform / epilogue of the convolutions */
 #define SPK_IN_AFFINE_RELU 1 /* input tile = max(in*in_scale[c] + in_shift[c], 0): BN+ReLU of the producer, fused */
@@ -40,12 +44,12 @@ const char* spk_last_error(void);
                                 output gradient this launch produces (dz = out * mask; mask = bn_act > 0, or
                                 bn_raw*scale+shift > 0 when bn_act is NULL; bn4 = [mean, invstd, scale, shift][Cout]) */
 
-/* kernel form (results are bit-identical to the plain kernel on the same tile) */
-#define SPK_CONV_WS 128      /* producer / consumer form of spk_conv_mfma (split != 0, 9 taps, kc = 1; flags bits 8-9 = log2 of
+/* kernel form (results are bit-identical to the plain kernel on the same tile); "experimental" = needs spk_build_flags() & 1 */
+#define SPK_CONV_WS 128      /* experimental: producer / consumer form of spk_conv_mfma (split != 0, 9 taps, kc = 1; flags bits 8-9 = log2 of
                                 its consumer-wave channel groups) and of spk_conv_wgrad (split = 3, 3x3) */
 #define SPK_CONV_PIPE 1024   /* in-wave pipelined form: spk_conv_mfma (split = 3, 9 taps, kc = 1, <= 576 halo pixels, two halo
-                                tiles in LDS; with SPK_IN_BNBWD: in_mask given, MT*NT <= 4) and spk_conv_wgrad (split = 3, 3x3,
-                                tile of 1 or 2 k-steps of 16 pixels per wave group) */
+                                tiles in LDS; plain or f16 pair input); experimental: with SPK_IN_BNBWD (in_mask given, MT*NT <= 4)
+                                and for spk_conv_wgrad (split = 3, 3x3, tile of 1 or 2 k-steps of 16 pixels per wave group) */
 
 #define SPK_WGRAD_GROUPS 2048 /* spk_conv_wgrad, split = 3: 1x1: the kernel that gives a block 1 << (flags bits 12-13) = 2 or 4
                                 groups of 32 input channels (Cin % (32 * groups) == 0, WN 2 or 4, tile <= 64 pixels); 3x3: the

@@ -143,6 +143,9 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE((flags & SPK_CONV_WS) || lds_bytes <= 160 * 1024, "spk_conv_mfma: halo tile %dx%d needs %zu B of LDS", a.halo_h, a.halo_w, lds_bytes);
     hipStream_t st = (hipStream_t)stream;
     if (flags & SPK_CONV_WS) {
+#ifndef SPK_EXPERIMENTAL
+        SPK_REQUIRE(false, "spk_conv_mfma: the wave-specialised kernel is an experimental form: build with SPK_EXPERIMENTAL=1 (spk_build_flags)");
+#else
         SPK_REQUIRE(split != 0 && kc == 1 && ntaps == 9, "spk_conv_mfma: the wave-specialised kernel needs bf16-split operands, 9 taps and kc = 1");
         for (int t = 0; t < 9; ++t) {
             const long long off = (long long)a.tap_w[t] * (Cin >> 4) * nterm * (Cout >> 5) * 256;     // [tap][Cin/16][term][Cout/32][256 floats]
@@ -150,6 +153,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
             a.tap_boff[t] = (int)off;
         }
         return spk_launch_conv_ws(a, MT, NT, ws_wc, split, lp4, st);
+#endif
     }
     if (flags & SPK_CONV_PIPE) {
         SPK_REQUIRE(split == 3 && kc == 1 && ntaps == 9, "spk_conv_mfma: the pipelined kernel needs f16x3 operands, 9 taps and kc = 1");

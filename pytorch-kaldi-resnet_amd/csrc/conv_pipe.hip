@@ -5,6 +5,10 @@
 template <int MT, int NT>
 static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
     if (a.flags & SPK_IN_BNBWD) {
+#ifndef SPK_EXPERIMENTAL
+        spk_set_error("spk_conv_mfma: the pipelined fused-BatchNorm-backward kernel is an experimental form: build with SPK_EXPERIMENTAL=1");
+        return -1;
+#else
         // fused BatchNorm backward: the sign-bit form only (the form that recomputes the mask from the raw tensor has more
         // VALU work per item than a tap has MFMA shadow and measured slower than conv_mfma_kernel), register tiles <= 2 x 2
         if constexpr (MT * NT <= 4) {
@@ -14,6 +18,7 @@ static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
             spk_set_error("spk_conv_mfma: no pipelined fused-BatchNorm-backward kernel for MT=%d NT=%d", MT, NT);
             return -1;
         }
+#endif
     } else if (a.flags & SPK_IN_PRESPLIT)        // f16 pair input: staging by plain copy
         hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
     else

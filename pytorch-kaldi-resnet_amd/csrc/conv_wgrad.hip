@@ -322,6 +322,10 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
                 a.halo_h, a.halo_w, 32 * WGRAD_NX);
     SPK_REQUIRE(TH * TW <= (256 / (8 * WN)) * WGRAD_ND, "spk_conv_wgrad: tile %dx%d exceeds the %d-pixel dY prefetch window (WN=%d)",
                 TH, TW, (256 / (8 * WN)) * WGRAD_ND, WN);
+#ifndef SPK_EXPERIMENTAL
+    SPK_REQUIRE(!(flags & (SPK_CONV_PIPE | SPK_CONV_WS)),
+                "spk_conv_wgrad: the pipelined / producer-consumer weight gradients are experimental forms: build with SPK_EXPERIMENTAL=1");
+#else
     if (flags & SPK_CONV_PIPE) {
         SPK_REQUIRE(split == 3 && ksize == 3, "spk_conv_wgrad: the pipelined kernel exists for 3x3 in the f16x3 mode");
         a.flags = flags & ~SPK_CONV_PIPE;
@@ -332,6 +336,7 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
         a.flags = flags & ~SPK_CONV_WS;
         return spk_launch_wgrad_ws(a, WN, (hipStream_t)stream);
     }
+#endif
     if (split) return spk_launch_wgrad_split(a, WN, split, (hipStream_t)stream);
     const int ntaps = ksize * ksize;
     const int WK = 4 / WN;

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
 }
 
 
+#ifdef SPK_EXPERIMENTAL
 // ---- producer / consumer form (f16x3 operands) ---------------------------------------------------------------------------
 // Measured on MI355X (tools/wg_abl.sh, 128-channel 20x75 layer): the kernel above takes 0.43 ms, of which the K loop alone
 // (fragment reads + MFMAs) is 0.28 ms and the staging alone (address arithmetic, loads, fp16 split, LDS writes, barriers)
@@ -570,6 +571,8 @@ int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st) {
     if (WN == 2) return launch_ws<9, 2, 2>(a, st);
     return launch_ws<9, 1, 4>(a, st);
 }
+
+#endif   // SPK_EXPERIMENTAL
 
 template <int NTAPS, int WK, int WN>
 static int launch_one(const WgradArgs& a, int split, hipStream_t st) {

@@ -25,6 +25,7 @@ _SIGS = {
     "spk_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "spk_pack_conv_weight_split": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "spk_pack_job_bytes": [],
+    "spk_build_flags": [],
     "spk_pack_conv_weights_batched": [_P, _I, _I, _I, _P],
     "spk_conv_mfma": [_P] * 21 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P, _P, _P, _P],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 16 + [_P, _P, _P],
@@ -102,6 +103,11 @@ def lib():
             fn.restype = ctypes.c_int
         _lib = l
     return _lib
+
+
+def has_experimental():
+    """the library was built with SPK_EXPERIMENTAL=1: the measured, not-faster kernel forms are present"""
+    return bool(lib().spk_build_flags() & 1)
 
 
 def exported_symbols():

@@ -165,6 +165,12 @@ LABEL_SHAPES = os.environ.get("SPK_LABEL_SHAPES", "0") == "1"      # diagnostic:
 WS_FORCE = None        # tests / sweeps: (TH, TW, MT, NT, WC) applied to every eligible launch
 
 
+def _experimental():
+    """the kernel forms behind SPK_CONV_WS / SPK_PIPE_BNBWD / SPK_WGRAD_PIPE / SPK_WGRAD_WS exist only in a library built with
+    SPK_EXPERIMENTAL=1 (python pytorch-kaldi-resnet_amd/build.py --experimental)"""
+    return hip.has_experimental()
+
+
 SPLIT_1X1 = os.environ.get("SPK_SPLIT_1X1", "1") == "1"
 
 
@@ -255,7 +261,8 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     pipe_fused = (PIPE_CONV and PIPE_BNBWD and split == 3 and in_bnbwd is not None and len(in_bnbwd) > 4 and MT * NT <= 4
                   and Cout <= 128 and WS_FORCE is None and WS_CONV != "1" and not side_presplit)
     ws_on = (WS_CONV == "1" or WS_FORCE is not None or (
-        WS_CONV == "auto" and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT and not pipe_fused))
+        WS_CONV == "auto" and _experimental() and split == 3 and in_bnbwd is not None and Cout >= WS_AUTO_MIN_COUT
+        and not pipe_fused))
     if side_presplit or in_presplit:
         ws_on = False            # f16 pair tensors: conv_mfma_kernel / conv_pipe_kernel only
     if split and ws_on and len(taps) >= WS_MIN_TAPS and ips == 1:

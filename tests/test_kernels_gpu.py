@@ -23,6 +23,14 @@ def ops():
     return _ops
 
 
+def needs_experimental():
+    """the producer / consumer and the other measured-not-faster kernel forms are compiled only with SPK_EXPERIMENTAL=1
+    (python pytorch-kaldi-resnet_amd/build.py --experimental, then SPK_LIB=.../variants/libspkhip_exp.so)"""
+    from pytorch_kaldi_resnet_amd import hip
+    if not hip.has_experimental():
+        pytest.skip("library built without SPK_EXPERIMENTAL")
+
+
 def rnd(seed, *shape, scale=1.0, shift=0.0):
     n = int(np.prod(shape))
     return torch.from_numpy(((W.hash_uniform(seed, 1, n) * 2 - 1) * scale + shift).astype(np.float32).reshape(shape))
@@ -197,6 +205,7 @@ def test_wave_specialised_conv_equals_the_reference_kernel(ops, layout, shape, w
     BN+ReLU, BN statistics), plain data gradient with shortcut add, and the fused BatchNorm-backward data gradient with
     sign masks, side output and BN-backward statistics.  Same MFMA order per accumulator => the convolution outputs are
     bit-identical; the per-wave statistics rows are grouped differently, so they are compared after reduction."""
+    needs_experimental()
     MT, NT, WC = layout
     B, C, H, Wd, stride = shape
     old = (ops.SPLIT, ops.WS_CONV, ops.WS_FORCE)
@@ -247,6 +256,7 @@ def test_wave_specialised_wgrad_equals_the_reference_kernel(ops, shape):
     conv_wgrad_pipe_kernel (the next region staged inside the K loop of the current one, csrc/conv_wgrad_pipe.hip)
     against conv_wgrad_split_kernel on the same tile and the same slab count: same MFMA order per accumulator and the
     same slab reduce => the weight gradients are bit-identical (with and without the fused BN + ReLU on X)."""
+    needs_experimental()
     from pytorch_kaldi_resnet_amd import tiling
     B, Cin, Cout, H, Wd, stride = shape
     old = (ops.SPLIT, ops.WS_WGRAD, ops.WS_WGRAD_BLOCKS, ops.PIPE_WGRAD, ops.GROUPED_3X3)
@@ -293,8 +303,10 @@ def test_pipelined_conv_equals_the_reference_kernel(ops, shape):
     for the forward (fused input BN + ReLU, epilogue affine / add / ReLU) and the plain data gradient (stride 1 and 2)."""
     B, Cin, Cout, H, Wd, stride = shape
     from pytorch_kaldi_resnet_amd import tiling
+    from pytorch_kaldi_resnet_amd import hip
     old = (ops.SPLIT, ops.PIPE_CONV, ops.WS_CONV, ops.PIPE_BNBWD)
-    ops.SPLIT, ops.WS_CONV, ops.PIPE_BNBWD = 3, "0", True
+    # (the pipelined form of the FUSED BatchNorm-backward data gradient is an experimental kernel: compared only when built)
+    ops.SPLIT, ops.WS_CONV, ops.PIPE_BNBWD = 3, "0", hip.has_experimental()
     real_tile = tiling.conv_tile
 
     def tile_2x2_for_fused(*key, mode=0, split=0):           # the fused pipelined kernel exists for register tiles <= 2 x 2
@@ -770,3 +782,27 @@ def test_scoring_backend_on_device(ops, gold_dir, tmp_path):
     np.testing.assert_allclose(mu.cpu().numpy(), [2.5, 0.5], rtol=1e-6)
     with pytest.raises(RuntimeError):
         ops.topk_mean_std(x, 6)
+
+
+def test_experimental_kernel_forms_in_their_variant_library():
+    """The producer / consumer convolution and weight gradient, the in-wave pipelined weight gradient and the in-wave pipelined
+    fused-BatchNorm-backward data gradient were measured and did not pay; they are compiled only with
+    SPK_EXPERIMENTAL=1.  __graft_entry__.build() builds that variant library next to the product one; their bit-identity tests
+    (skipped above when the loaded library lacks them) run here in a child process that loads it through SPK_LIB."""
+    import subprocess
+    import sys
+    from pytorch_kaldi_resnet_amd import hip
+    if hip.has_experimental():
+        pytest.skip("the loaded library already contains the experimental forms: their tests ran above")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "pytorch-kaldi-resnet_amd", "variants", "libspkhip_exp.so")
+    if not os.path.exists(lib):
+        pytest.skip("variants/libspkhip_exp.so not built (python __graft_entry__.py build)")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "wave_specialised or pipelined_conv"], env=dict(os.environ, SPK_LIB=lib), capture_output=True, text=True,
+                       timeout=900)
+    tail = r.stdout[-1500:] + r.stderr[-500:]
+    assert r.returncode == 0, tail
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 30, tail                  # 28 + 5 + 6 cases; a few layouts skip themselves by design
