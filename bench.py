@@ -18,7 +18,8 @@ Prints ONE JSON line (see the repo contract) with two extra objects:
                  8 TB/s of HBM; the larger fraction names the binding one
   f16_window   - (f16x3 mode) counters of the operand-scale windows of one full-size step: staged values that would
                  saturate fp16 (must be 0: every scale comes from an absmax or a rigorous bound) and the share that
-                 falls below the two-term window (carried with 11 instead of 22 significand bits)
+                 has a subnormal low term (the matrix instruction keeps fp16 subnormals: 11..22 significand bits, absolute
+                 error <= bound * 2^-39)
   cpu_baseline - the CPU oracle (oracle/spk_oracle.py, a torch-CPU port of the reference path) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N = 1 only): 2 warm-ups + median of 5
                  steps of the C2-micro (bs 32, T = 300) and the C1 shape (bs 32, T = 200), train step and predict
@@ -545,12 +546,13 @@ def main():
         tot, sat, lo_lost, hi_sub = eng.window_counts.tolist()
         eng.window_counts = None
         opt.zero_grad(set_to_none=True)
-        f16_window = {"staged_values": tot, "saturated": sat, "low_term_lost_frac": round(lo_lost / max(tot, 1), 8),
+        f16_window = {"staged_values": tot, "saturated": sat, "low_term_subnormal_frac": round(lo_lost / max(tot, 1), 8),
                       "high_term_subnormal_frac": round(hi_sub / max(tot, 1), 8),
                       "note": "values staged by f16x3 matrix-core kernels in one step, judged under the scale slot of their consumer "
-                              "(absmax of the tensor or a rigorous bound): saturated must be 0; a lost low term = the value is "
-                              "carried with 11 instead of 22 significand bits (absolute error <= bound * 2^-29)"}
-        log("f16 windows: %d staged values, %d saturated, %.5f %% low term lost" % (tot, sat, 100.0 * lo_lost / max(tot, 1)))
+                              "(absmax of the tensor or a rigorous bound): saturated must be 0; a subnormal low term = the value "
+                              "carries between 11 and 22 significand bits (the matrix instruction keeps fp16 subnormals: absolute "
+                              "error <= bound * 2^-39)"}
+        log("f16 windows: %d staged values, %d saturated, %.5f %% low term subnormal" % (tot, sat, 100.0 * lo_lost / max(tot, 1)))
         if sat:
             raise SystemExit("bench: %d staged values saturate fp16 under their scale slot - an operand-scale bound is wrong" % sat)
 

@@ -162,6 +162,13 @@ if _os.environ.get("SPK_FUSED_TILE"):
     _FUSED_TILE_OVERRIDE = ((_oh, _ow, 1, 3, 3, 9, _co), tuple(int(x) for x in _v.split(",")))
 
 
+# ... and SPK_PLAIN_TILE="OH,OW,ntaps,Cout:TH,TW,MT,NT" the tile of the plain launches of a shape (any stride)
+_PLAIN_TILE_OVERRIDE = None
+if _os.environ.get("SPK_PLAIN_TILE"):
+    _k, _v = _os.environ["SPK_PLAIN_TILE"].split(":")
+    _PLAIN_TILE_OVERRIDE = (tuple(int(x) for x in _k.split(",")), tuple(int(x) for x in _v.split(",")))
+
+
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     """mode 1 = data gradient with the BatchNorm backward fused into its input staging (heavier staging: it may prefer
     wider channel tiles); table keys carry the mode as an 8th element and fall back to the plain entry.  split != 0
@@ -169,6 +176,8 @@ def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
     if mode and _FUSED_TILE_OVERRIDE and key == _FUSED_TILE_OVERRIDE[0]:
         return _FUSED_TILE_OVERRIDE[1]
+    if not mode and _PLAIN_TILE_OVERRIDE and (OH, OW, ntaps, Cout) == _PLAIN_TILE_OVERRIDE[0]:
+        return _PLAIN_TILE_OVERRIDE[1]
     if split:
         if mode and key + (mode,) in FORCE_CONV_SPLIT:
             return FORCE_CONV_SPLIT[key + (mode,)]
