@@ -51,6 +51,10 @@ int spk_build_flags(void);
                                 tiles in LDS; plain or f16 pair input); experimental: with SPK_IN_BNBWD (in_mask given, MT*NT <= 4)
                                 and for spk_conv_wgrad (split = 3, 3x3, tile of 1 or 2 k-steps of 16 pixels per wave group) */
 
+#define SPK_CONV_M16 (1 << 17) /* with SPK_CONV_PIPE on spk_conv_mfma (plain or f16 pair input, MT = 3, NT = 2, <= 512 halo pixels,
+                                Cin % 32 == 0): the same kernel on v_mfma_f32_16x16x32_f16, two taps per 32-deep K step.  Same products,
+                                another summation order: equal to the other forms within fp32 accumulation error, not bit-identical */
+
 #define SPK_WGRAD_GROUPS 2048 /* spk_conv_wgrad, split = 3: 1x1: the kernel that gives a block 1 << (flags bits 12-13) = 2 or 4
                                 groups of 32 input channels (Cin % (32 * groups) == 0, WN 2 or 4, tile <= 64 pixels); 3x3: the
                                 2 x 2 (input-channel group x output-channel group) wave layout (groups = 2, WN = 2) */

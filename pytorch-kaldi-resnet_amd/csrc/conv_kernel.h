@@ -86,20 +86,39 @@ struct ConvArgs {
 // that follows an MFMA in the same instruction stream does; staging done as a separate phase - or by separate producer
 // waves - is therefore paid in full on top of the matrix time.
 #define PIPE_D 3
+#ifndef PIPE16_VPM
+#define PIPE16_VPM 2    // the same for the 16x16x32 form: its matrix instruction leaves 8 of its 16 cycles to the vector issue
+#endif
 #ifndef PIPE_VPM
 #define PIPE_VPM 6      // VALU instructions scheduled behind every MFMA of a pipelined tap (2 / 4 / 6 / 8 measured: 57.08 / 57.29 / 56.94 / 56.9 ms per step)
 #endif
 // PRE (PIPE only): the input is an f16 pair tensor (spk_common.h): staging item = one 16-byte load + two 8-byte LDS writes, no
 // conversion - the data gradients whose BatchNorm backward ran as a separate pass (spk_bn_bwd_apply with pair output).
 // The non-pipelined f16x3 kernels take pair tensors through the run-time flag SPK_IN_PRESPLIT.
-template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false>
+// M16 (PIPE only, plain or pair input): the matrix instruction is v_mfma_f32_16x16x32_f16 instead of 32x32x16 - the same
+// multiply-adds per cycle, but in these power-limited loops the chip holds a higher clock on it (tools/probe/shape_probe.hip:
+// 1.15 x at one wave per SIMD, 1.25 x at two, in a loop of this kernel's shape).  Its K step is 32 deep; a staged plane stays 16
+// channels (two 32-channel tiles would not leave two blocks per CU), so a K step PAIRS TWO TAPS of the plane: lanes 0-31 carry the
+// 16 channels of tap t, lanes 32-63 those of tap t'.  Nine taps are odd: two planes are walked together - (0,1)(2,3)(4,5)(6,7) of
+// the even plane, then (8 | 0 of the odd plane), then (1,2)(3,4)(5,6)(7,8) - nine steps per plane pair.  The step that straddles
+// the planes reads both LDS slots, so the even slot is refilled only after it (one more barrier per plane pair).  The packed
+// weights keep their order: a lane picks its tap's 16-byte piece by address.  Inside a pixel the LDS image is [8-channel
+// half][term] instead of [term][half], and the 16 rows of a tile are a permutation of 16 consecutive pixels (even pixels on rows
+// 4-11): with both, the four 16-lane groups of a ds_read_b128 are conflict-free (the natural order is 2-way).
+template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false, bool M16 = false>
 static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
     constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
+    static_assert(!M16 || (PIPE && !BNBWD && SPLIT == 3), "M16: the pipelined f16x3 kernel with a plain or pair input");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // M16: row of the 16 x 16 tile -> pixel of the 16-pixel group (rows 4..11 <-> even pixels), and the inverse for the epilogue
+    auto pix_of_row16 = [](int row) {
+        const int q = (row + 12) & 15;
+        return ((q & 7) << 1) | (q >> 3);
+    };
     // f16x3: input scale (a power of two) and the factor that takes the accumulators back to fp32 units
     // (two factors: the product of the scales may leave the fp32 range, each reciprocal is an exact power of two)
     float sig = 1.f, inv_sig = 1.f, inv_wsig = 1.f;
@@ -142,7 +161,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int n0 = cg * NT * 32;
     const int flags = a.flags;
 
-    int lbase[MT], obase[MT], opix[MT];      // opix: output pixel index (the masks are addressed per pixel)
+    int lbase[M16 ? 2 * MT : MT], obase[MT], opix[MT];      // opix: output pixel index (the masks are addressed per pixel)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int q = (wave * MT + i) * 32 + r;
@@ -151,18 +170,31 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         const int ly = qq / a.TW, lx = qq - ly * a.TW;
         const int oy = oy0 + ly, ox = ox0 + lx;
         v = v && oy < a.OH && ox < a.OW;
-        lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + h;   // 16-byte units
+        if constexpr (!M16) lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + h;   // 16-byte units
         opix[i] = (b * a.OHf + oy * a.OS + a.ooy) * a.OWf + ox * a.OS + a.oox;
         obase[i] = v ? opix[i] * a.Cout + n0 : -1;
     }
+    if constexpr (M16) {
+        // A fragment of a 16-row tile: lane l reads the 8 channels of half (l >> 4) & 1 of pixel pix_of_row16(l & 15); the tap
+        // (lanes 32-63: the step's second tap) is added per step
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int q = (wave * 2 * MT + i) * 16 + pix_of_row16(lane & 15);
+            const int qq = q < npix_tile ? q : 0;
+            const int ly = qq / a.TW, lx = qq - ly * a.TW;
+            lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + 2 * ((lane >> 4) & 1);
+        }
+    }
 
-    f32x16 acc[MT][NT];
+    using AccT = std::conditional_t<M16, f32x4, f32x16>;
+    constexpr int AM = M16 ? 2 * MT : MT, AN = M16 ? 2 * NT : NT, AE = M16 ? 4 : 16;
+    AccT acc[AM][AN];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < AM; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < AN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
     const int nchunks = a.Cin / (CK * a.kc);
     const int halo_pix = a.halo_h * a.halo_w;
@@ -171,9 +203,15 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int quad = tid & (TPP - 1);   // this thread's float4 of channels within a staged pixel
     const int prow = tid / TPP;         // and its pixel slot within a staging pass
     auto store_pair = [&](float* plane, int p, uint2 t0, uint2 t1) {      // f16x3: the two terms of one float4 of channels
-        uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;      // [term][CK ch]: CK*2 bytes per term
-        dst[0] = t0;
-        dst[CK / 4] = t1;
+        if constexpr (M16) {
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + (quad >> 1) * 4 + (quad & 1);   // [8-channel half][term][8 ch]
+            dst[0] = t0;
+            dst[2] = t1;
+        } else {
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;      // [term][CK ch]: CK*2 bytes per term
+            dst[0] = t0;
+            dst[CK / 4] = t1;
+        }
     };
     auto store_px = [&](float* plane, int p, f32x4 w) {
         if constexpr (SPLIT == 0) {
@@ -317,6 +355,215 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         }
     };
 
+    if constexpr (M16) {
+        // ---- 16x16x32 K loop (see the note above the template): a.ntaps == 9, a.kc == 1, at most 8 x 64 halo pixels and an
+        // even number of planes (checked by the launcher).  A step = 2 * MT row tiles x 2 * NT column tiles x 3 products; the
+        // staging items of the next plane are dealt one per HALF step (MT row tiles: the matrix cycles of one tap of the
+        // 32x32x16 form), eight items per plane.
+        const f32x4* lds4 = (const f32x4*)lds;
+        const int plane4 = halo_pix * LP4;                           // 16-byte units per slot
+        float* dump = lds + 2 * plane_floats;
+        const int hik = lane >> 5;                                   // this lane's unit of a step's pair
+        const bool aff = (flags & SPK_IN_AFFINE_RELU) != 0;
+        const float floor_v = aff ? 0.f : -__builtin_inff();         // ReLU only with the fused input transform
+        // packed weights [tap][Cin/16][term][Cout/32][64 lanes][8 fp16] (pack.hip): the 16 bytes with input channels
+        // 8 kh .. 8 kh + 7 of (tap, plane) for output channel n are lane slot (n & 31) + 32 kh of tile n >> 5
+        const int grp_stride = NTERM * cout32 * 256, tap_stride = (a.Cin >> 4) * grp_stride, term_stride = cout32 * 256;
+        const float* wq = a.wpk + (size_t)(cg * NT) * 256 + ((lane & 15) + 32 * ((lane >> 4) & 1)) * 4;
+        // the plane being staged (set per phase)
+        int cn = quad * 4;
+        float* nxt = dump;
+        bool more = false;
+        f32x4 scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
+        unsigned inbm = 0;
+        f32x4 pre[PIPE_D];
+        auto phase = [&](int chunk, int slot) {
+            more = chunk < nchunks;
+            cn = (more ? chunk : nchunks - 1) * CK + quad * 4;
+            nxt = lds + slot * plane_floats;
+            if (aff) {
+                scn = *(const f32x4*)(a.in_scale + cn);
+                shn = *(const f32x4*)(a.in_shift + cn);
+            }
+        };
+        // (the item geometry is loop-invariant; formed from an opaque copy of the thread's pixel slot so that the optimizer does
+        //  not keep eight items' addresses and flags in registers across the loop)
+        auto issue = [&](auto uc) {                                  // global load of staging item u of that plane
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u >= 8) return;
+            int pr = prow;
+            asm volatile("" : "+v"(pr));
+            const int p = min(pr + PPP * u, halo_pix - 1);
+            const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+            const int hx = p - hy * a.halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
+            inbm = (inbm & ~(1u << u)) | ((unsigned)ok << u);
+            const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
+            pre[u % PIPE_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+        };
+        auto finish = [&](auto uc) {                                 // transform + fp16 split + LDS write of item u (branch-free)
+            constexpr int u = decltype(uc)::value;
+            int pr = prow;
+            asm volatile("" : "+v"(pr));
+            const int p = pr + PPP * u;
+            const bool ok = (inbm >> u) & 1u;
+            const bool real = more & (p < halo_pix);
+            if constexpr (PRE) {
+                const uint4 bb = __builtin_bit_cast(uint4, pre[u % PIPE_D]);
+                const uint2 t0 = {ok ? bb.x : 0u, ok ? bb.y : 0u}, t1 = {ok ? bb.z : 0u, ok ? bb.w : 0u};
+                store_pair(real ? nxt : dump, real ? p : 0, t0, t1);
+            } else {
+                f32x4 w = pre[u % PIPE_D] * scn + shn;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
+                store_px(real ? nxt : dump, real ? p : 0, w);
+            }
+        };
+        f32x4 aq[2][NTERM];                  // A fragments of the current and of the next 16-row tile
+        f32x4 bx[NTERM][AN], by[NTERM][AN];  // B fragments of the current and of the next step
+        auto load_b = [&](f32x4 (*bf)[AN], int wsel) {
+            const float* wp = wq + wsel;
+#pragma unroll
+            for (int s = 0; s < NTERM; ++s)
+#pragma unroll
+                for (int j = 0; j < AN; ++j) bf[s][j] = *(const f32x4*)(wp + s * term_stride + (j >> 1) * 256 + (j & 1) * 64);
+        };
+        auto load_a = [&](f32x4* af, int i16, int osel) {
+#pragma unroll
+            for (int s = 0; s < NTERM; ++s) af[s] = lds4[lbase[i16] + osel + s];
+        };
+        // (opaque to the optimizer: it would otherwise hoist lbase[i] + offset for all nine steps out of the loop - 54 registers)
+        auto sel = [&](int x0, int x1) {
+            int v = hik ? x1 : x0;
+            asm volatile("" : "+v"(v));
+            return v;
+        };
+#define IC(n) std::integral_constant<int, n>{}
+        // One scheduling region per half step: MT * AN * 3 matrix instructions, the A fragments one row tile ahead, in the first
+        // half the B fragments of the next step, and one staging item (finish fin, issue fin + PIPE_D).  roll: after the last row
+        // tile of the step, read row tile 0 of the next step (not across a barrier that completes the slot it reads).
+        auto hstep = [&](auto half_c, auto fin_c, auto roll_c, const f32x4 (*bc)[AN], f32x4 (*bn)[AN], int w_next, int o_cur, int o_next) {
+            constexpr int half = decltype(half_c)::value, fin = decltype(fin_c)::value;
+            constexpr bool roll = decltype(roll_c)::value != 0;
+#pragma unroll
+            for (int ii = 0; ii < MT; ++ii) {
+                // One scheduling region per row tile: its AN * 3 matrix instructions in source order (four independent
+                // accumulators in rotation - a dependent 16x16x32 issued back to back waits for its predecessor), the A fragments
+                // of the NEXT row tile read first, and one piece of the other work: the B fragments of the next step + the global
+                // conversion and LDS write of a staging item (tile 0), the global load of the item PIPE_D later (tile 1).
+                const int i16 = half * MT + ii;
+                __builtin_amdgcn_sched_barrier(0);
+                if (i16 + 1 < 2 * MT) load_a(aq[(i16 + 1) & 1], i16 + 1, o_cur);
+                else if constexpr (roll) load_a(aq[0], 0, o_next);
+                __builtin_amdgcn_sched_barrier(0);      // (left to the scheduler the reads sink to their first use: no latency cover)
+                if (ii == 0) {
+                    if constexpr (half == 0) load_b(bn, w_next);
+#ifndef M16_NO_STAGE
+                    if constexpr (fin >= 0) finish(IC(fin));              // (reads pre[fin % PIPE_D] before issue below refills it)
+#endif
+                }
+#ifndef M16_NO_STAGE
+                if (ii == 1 % MT) {
+                    if constexpr (fin >= 0) issue(IC(fin + PIPE_D));
+                }
+#endif
+#pragma unroll
+                for (int sum = 1; sum >= 0; --sum)
+#pragma unroll
+                    for (int sa = 0; sa < NTERM; ++sa) {
+                        const int sb = sum - sa;
+                        if (sb < 0 || sb >= NTERM) continue;
+#pragma unroll
+                        for (int j = 0; j < AN; ++j) {
+                            acc[i16][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, aq[i16 & 1][sa]),
+                                                                                __builtin_bit_cast(f16x8, bc[sb][j]), acc[i16][j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0x7F7);      // everything but a matrix instruction may cross
+                        }
+                    }
+#ifdef M16_GROUPS
+                __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);              // the A fragments of the next row tile first
+#pragma unroll
+                for (int k = 0; k < AN * 3; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA (16 cycles, 8 of them hold the vector issue)
+                    __builtin_amdgcn_sched_group_barrier(0x002, PIPE16_VPM, 0);     // VALU instructions in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // (an LDS write of the item when one is ready)
+                }
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // offsets of a unit (plane c, tap t): A in LDS (16-byte units), B in the packed weights (floats)
+        auto ao = [&](int slot, int t) { return slot * plane4 + a.tap_off[t]; };
+        auto bo = [&](int c, int t) { return a.tap_w[t] * tap_stride + c * grp_stride; };
+        __syncthreads();
+        stage_chunk(0);                      // first plane: staged the plain way into slot 0
+        __syncthreads();
+        // (per-lane offsets of a step: formed where they are used - nine of them held across the loop cost nine registers)
+#define O0 sel(ao(0, 0), ao(0, 1))
+#define O1 sel(ao(0, 2), ao(0, 3))
+#define O2 sel(ao(0, 4), ao(0, 5))
+#define O3 sel(ao(0, 6), ao(0, 7))
+#define O4 sel(ao(0, 8), ao(1, 0))
+#define O5 sel(ao(1, 1), ao(1, 2))
+#define O6 sel(ao(1, 3), ao(1, 4))
+#define O7 sel(ao(1, 5), ao(1, 6))
+#define O8 sel(ao(1, 7), ao(1, 8))
+        load_b(bx, sel(bo(0, 0), bo(0, 1)));
+        load_a(aq[0], 0, O0);
+        for (int cp = 0; cp < nchunks; cp += 2) {
+            const int cn2 = cp + 2 < nchunks ? cp + 2 : cp + 1;      // after the last pair: a harmless re-fetch
+            // ---- even plane (slot 0): taps (0,1) (2,3) (4,5) (6,7); plane cp + 1 is staged into slot 1
+            phase(cp + 1, 1);
+            issue(IC(0));
+            issue(IC(1));
+            issue(IC(2));
+            hstep(IC(0), IC(0), IC(1), bx, by, sel(bo(cp, 2), bo(cp, 3)), O0, O1);
+            hstep(IC(1), IC(1), IC(1), bx, by, 0, O0, O1);
+            hstep(IC(0), IC(2), IC(1), by, bx, sel(bo(cp, 4), bo(cp, 5)), O1, O2);
+            hstep(IC(1), IC(3), IC(1), by, bx, 0, O1, O2);
+            hstep(IC(0), IC(4), IC(1), bx, by, sel(bo(cp, 6), bo(cp, 7)), O2, O3);
+            hstep(IC(1), IC(5), IC(1), bx, by, 0, O2, O3);
+            hstep(IC(0), IC(6), IC(1), by, bx, sel(bo(cp, 8), bo(cp + 1, 0)), O3, O4);
+            hstep(IC(1), IC(7), IC(0), by, bx, 0, O3, O4);
+            __syncthreads();                 // slot 1 is complete
+            load_a(aq[0], 0, O4);
+            // ---- (8 | 0 of the odd plane), then the odd plane (slot 1): (1,2) (3,4) (5,6) (7,8); plane cp + 2 goes to slot 0 once
+            // every wave is past the straddling step
+            phase(cp + 2, 0);
+            issue(IC(0));
+            issue(IC(1));
+            issue(IC(2));
+            hstep(IC(0), IC(-1), IC(1), bx, by, sel(bo(cp + 1, 1), bo(cp + 1, 2)), O4, O5);
+            hstep(IC(1), IC(-1), IC(1), bx, by, 0, O4, O5);
+            __syncthreads();                 // slot 0 is free
+            hstep(IC(0), IC(0), IC(1), by, bx, sel(bo(cp + 1, 3), bo(cp + 1, 4)), O5, O6);
+            hstep(IC(1), IC(1), IC(1), by, bx, 0, O5, O6);
+            hstep(IC(0), IC(2), IC(1), bx, by, sel(bo(cp + 1, 5), bo(cp + 1, 6)), O6, O7);
+            hstep(IC(1), IC(3), IC(1), bx, by, 0, O6, O7);
+            hstep(IC(0), IC(4), IC(1), by, bx, sel(bo(cp + 1, 7), bo(cp + 1, 8)), O7, O8);
+            hstep(IC(1), IC(5), IC(1), by, bx, 0, O7, O8);
+            hstep(IC(0), IC(6), IC(1), bx, by, sel(bo(cn2, 0), bo(cn2, 1)), O8, O0);
+            hstep(IC(1), IC(7), IC(0), bx, by, 0, O8, O0);
+            __syncthreads();                 // slot 0 is complete, slot 1 is free
+            load_a(aq[0], 0, O0);
+            // nine steps per pair: the two B buffers have swapped roles
+#pragma unroll
+            for (int s2 = 0; s2 < NTERM; ++s2)
+#pragma unroll
+                for (int j = 0; j < AN; ++j) bx[s2][j] = by[s2][j];
+        }
+#undef O0
+#undef O1
+#undef O2
+#undef O3
+#undef O4
+#undef O5
+#undef O6
+#undef O7
+#undef O8
+#undef IC
+    } else {
     f32x4 pb0[PIPE ? 2 : 1][NT], pb1[PIPE ? 2 : 1][NT], pb2[PIPE ? 2 : 1][NT];     // PIPE: B fragments, carried from chunk to chunk
     for (int ch = 0; ch < nchunks; ++ch) {
         if constexpr (SPLIT == 0) {
@@ -707,6 +954,8 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         }
     }
 
+    }   // !M16
+
     // ---- epilogue.  C/D layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane
     // holds ONE channel of 16 pixels.  Each wave transposes one m-tile at a time through a private LDS slab
     // [32 pixels][NT*32 + 4] so that a lane then owns 4 consecutive channels of one pixel: 16-byte global stores,
@@ -733,6 +982,27 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     }
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
     float out_mx = 0.f;
+    auto to_slab = [&](int i) {          // the accumulators of m-tile i (32 pixels x NT * 32 channels) -> this wave's slab
+        if constexpr (M16) {
+            // 16 x 16 tiles: col = lane & 15, row = 4 (lane >> 4) + e; tile rows are a permutation of the pixels (pix_of_row16)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * ii + pix_of_row16(4 * (lane >> 4) + e);
+#pragma unroll
+                    for (int j = 0; j < 2 * NT; ++j) slab[row * LW + j * 16 + (lane & 15)] = acc[2 * i + ii][j][e] * inv_sig * inv_wsig;
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
+                }
+        }
+    };
 #ifndef SPK_EPI_BATCH
 #define SPK_EPI_BATCH 1      // 0: A/B builds with the pass-by-pass epilogue everywhere (tools/variant.sh)
 #endif
@@ -745,13 +1015,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     if constexpr (!EPB) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
-                }
+            to_slab(i);
             // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
 #pragma unroll
             for (int k = 0; k < 32 / RPP; ++k) {
@@ -826,13 +1090,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         const bool f_add = (flags & SPK_EPI_ADD) != 0, f_bnb = (flags & SPK_EPI_BNBWD) != 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    slab[row * LW + j * 32 + r] = SPLIT == 3 ? acc[i][j][e] * inv_sig * inv_wsig : acc[i][j][e];
-                }
+            to_slab(i);
             // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
             if (!f_add && !f_bnb) {
                 // no global reads in this epilogue (forward convolutions): pass by pass
@@ -972,7 +1230,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // the in-wave pipelined form (f16x3 operands; conv_pipe.hip)
 // BITS (fused BatchNorm backward only): the ReLU mask comes as sign bits (in_mask); otherwise it is recomputed from the raw
 // conv output (in_act is not supported here: such launches stay on conv_mfma_kernel)
-template <int MT, int NT, bool BNBWD, bool BITS = false, bool PRE = false>
+template <int MT, int NT, bool BNBWD, bool BITS = false, bool PRE = false, bool M16 = false>
 __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(ConvArgs a) {        // two blocks per CU: 256 registers per lane
-    conv_body<MT, NT, BNBWD, 3, true, BITS, PRE>(a);
+    conv_body<MT, NT, BNBWD, 3, true, BITS, PRE, M16>(a);
 }

@@ -85,6 +85,7 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
     SPK_REQUIRE(split != 3 || in_amax, "spk_conv_mfma: the f16x3 operand mode needs in_amax (slot with the float bits of the staged tensor's absmax or of an upper bound)");
     SPK_REQUIRE(!(flags & SPK_IN_PRESPLIT) || (split == 3 && !(flags & (SPK_IN_AFFINE_RELU | SPK_IN_BNBWD | SPK_CONV_WS))),
                 "spk_conv_mfma: IN_PRESPLIT (f16 pair input) needs the f16x3 mode, a plain input, and not the wave-specialised kernel");
+    SPK_REQUIRE(!(flags & SPK_CONV_M16) || (flags & SPK_CONV_PIPE), "spk_conv_mfma: CONV_M16 is a form of the pipelined kernel (CONV_PIPE)");
     SPK_REQUIRE(!(flags & SPK_SIDE_PRESPLIT) || ((flags & SPK_IN_BNBWD) && split == 3 && !(flags & (SPK_CONV_WS | SPK_CONV_PIPE))),
                 "spk_conv_mfma: SIDE_PRESPLIT (f16 pair side output) exists for the fused BatchNorm-backward form of conv_mfma_kernel in the f16x3 mode");
     ConvArgs a;
@@ -163,6 +164,11 @@ extern "C" int spk_conv_mfma(const float* in, const float* wpk, float* out, cons
         size_t lds2 = (2 * (size_t)a.halo_h * a.halo_w + 1) * lp4 * 16;      // two tiles + the dump pixel
         if (lds2 < red_bytes) lds2 = red_bytes;
         SPK_REQUIRE(lds2 <= 160 * 1024, "spk_conv_mfma: two halo tiles %dx%d need %zu B of LDS", a.halo_h, a.halo_w, lds2);
+        if (flags & SPK_CONV_M16) {
+            SPK_REQUIRE(!(flags & SPK_IN_BNBWD), "spk_conv_mfma: CONV_M16 excludes the fused BatchNorm backward");
+            SPK_REQUIRE(a.halo_h * a.halo_w <= 8 * 64, "spk_conv_mfma: CONV_M16 stages at most 512 halo pixels (%d x %d)", a.halo_h, a.halo_w);
+            SPK_REQUIRE((Cin / SPK_SPLIT_CK) % 2 == 0, "spk_conv_mfma: CONV_M16 walks the 16-channel planes in pairs");
+        }
         a.flags = flags & ~SPK_CONV_PIPE;
         return spk_launch_conv_pipe(a, lds2, MT, NT, st);
     }

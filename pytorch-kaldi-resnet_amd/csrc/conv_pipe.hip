@@ -19,6 +19,18 @@ static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
             return -1;
         }
 #endif
+    } else if (a.flags & SPK_CONV_M16) {         // 16x16x32 matrix instruction, taps paired (conv_kernel.h, M16)
+        ConvArgs b = a;
+        b.flags = a.flags & ~SPK_CONV_M16;
+        if constexpr (MT == 3 && NT == 2) {
+            if (a.flags & SPK_IN_PRESPLIT)
+                hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, true, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, b);
+            else
+                hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, false, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, b);
+        } else {
+            spk_set_error("spk_conv_mfma: no 16x16x32 pipelined kernel for MT=%d NT=%d", MT, NT);
+            return -1;
+        }
     } else if (a.flags & SPK_IN_PRESPLIT)        // f16 pair input: staging by plain copy
         hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
     else

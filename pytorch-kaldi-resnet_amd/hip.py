@@ -12,6 +12,7 @@ IN_AFFINE_RELU, EPI_AFFINE, EPI_ADD, EPI_RELU, EPI_STATS, EPI_BNBWD, IN_BNBWD, C
 CONV_PIPE = 1024
 WGRAD_GROUPS = 2048        # spk_conv_wgrad flags: 1x1 f16x3 kernel with 1 << (bits 12-13) input-channel groups per block
 IN_PRESPLIT, SIDE_PRESPLIT, DY_PRESPLIT = 1 << 14, 1 << 15, 1 << 16     # f16 pair tensors (include/spkhip.h)
+CONV_M16 = 1 << 17      # 16x16x32 form of the pipelined convolution
 MASK_NONE, MASK_ACT, MASK_RAW, MASK_BITS = 0, 1, 2, 3
 
 _P = ctypes.c_void_p

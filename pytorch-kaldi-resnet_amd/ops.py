@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import hip, tiling
-from .hip import (CONV_PIPE, CONV_WS, DY_PRESPLIT, IN_PRESPLIT, SIDE_PRESPLIT, WGRAD_GROUPS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU,
+from .hip import (CONV_M16, CONV_PIPE, CONV_WS, DY_PRESPLIT, IN_PRESPLIT, SIDE_PRESPLIT, WGRAD_GROUPS, EPI_ADD, EPI_AFFINE, EPI_BNBWD, EPI_RELU,
                   EPI_STATS, IN_AFFINE_RELU, IN_BNBWD, MASK_ACT, MASK_NONE, MASK_RAW,
                   call, ptr, stream)
 
@@ -140,6 +140,8 @@ assert WS_CONV in ("0", "1", "auto"), "SPK_CONV_WS must be 0, 1 or auto"
 WS_AUTO_MIN_COUT = 128
 # in-wave pipelined staging (conv_pipe_kernel): on by default for the f16x3 3x3 launches it covers; SPK_CONV_PIPE=0 disables
 PIPE_CONV = os.environ.get("SPK_CONV_PIPE", "1") == "1"
+# its v_mfma_f32_16x16x32_f16 form (two taps per K step; the chip holds a higher clock on that instruction shape)
+PIPE_M16 = os.environ.get("SPK_PIPE_M16", "0") == "1"
 # the same for the 3x3 weight gradients (conv_wgrad_pipe_kernel): opt-in.  Bit-identical, but no faster than
 # conv_wgrad_split_kernel (+2..6 % on the 32/64-channel layers, -1..-12 % elsewhere, profiles/r02_wgrad_ablation.log): a tap of
 # the weight gradient has three matrix instructions against ~60 VALU instructions of a staging item, so the VALU stream sets the
@@ -286,6 +288,10 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
             and (2 * halo9 + 1) * 80 <= PIPE_MAX_LDS and Cin >= PIPE_MIN_CIN)
     if pipe:
         flags |= CONV_PIPE
+    # its 16x16x32 form (conv_kernel.h, M16): the (3, 2) register tile, at most eight staging items per plane
+    m16 = pipe and PIPE_M16 and in_bnbwd is None and (MT, NT) == (3, 2) and halo9 <= 512 and IS == 1
+    if m16:
+        flags |= CONV_M16
     if ws is not None:
         flags |= CONV_WS | ({1: 0, 2: 1, 4: 2}[WC] << 8)
     if in_affine is not None:
@@ -335,7 +341,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
          _iarr(dys), _iarr(dxs), _iarr(tws), TH, TW, MT, NT, kc, ips, flags, split, ptr(in_amax), ptr(out_amax), ptr(side_amax),
          stream(),
          label=(("conv_ws_kernel<%d,%d,%d,%s,%d>" % (MT, NT, WC, "true" if in_bnbwd is not None else "false", split)) if ws is not None
-                else ("conv_pipe_kernel<%d,%d,false,false%s>" % (MT, NT, ",true" if in_presplit else "") if in_bnbwd is None
+                else ("conv_pipe_kernel<%d,%d,false,false%s>" % (MT, NT, (",true,true" if in_presplit else ",false,true") if m16 else (",true" if in_presplit else "")) if in_bnbwd is None
                       else "conv_pipe_kernel<%d,%d,true,true>" % (MT, NT)) if pipe
                 else "conv_mfma_kernel<%d,%d,%s,%d>" % (MT, NT, "true" if in_bnbwd is not None else "false", split)) + (
              " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),

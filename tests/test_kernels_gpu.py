@@ -361,6 +361,69 @@ def test_pipelined_conv_equals_the_reference_kernel(ops, shape):
         tiling.conv_tile = real_tile
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 75, (20, 19)), (2, 128, 128, 20, 75, (20, 19)), (2, 256, 256, 10, 38, (10, 38)),
+                                   (1, 64, 128, 23, 41, (16, 24)), (1, 128, 64, 17, 50, (8, 48)), (3, 64, 192, 9, 20, (10, 38))])
+def test_pipelined_conv_16x16x32_form(ops, shape):
+    """conv_pipe_kernel<3,2,..,M16> (v_mfma_f32_16x16x32_f16, two taps per K step, planes walked in pairs; csrc/conv_kernel.h)
+    against the 32x32x16 form on the same tile: the same products in another summation order - equal within fp32 accumulation
+    error (2e-6 of the output range per element), as close to fp64 as the other form, and NOT required bit-identical.  Forward with
+    fused input BN + ReLU and statistics, forward with epilogue affine / add / ReLU, plain data gradient with shortcut add, and
+    the pair-input data gradient with masked add + BatchNorm-backward statistics (the batched-read epilogue).  Tiles with ragged
+    edges, 6 / 8 / 16 planes of 16 channels."""
+    B, Cin, Cout, H, Wd, tile = shape
+    from pytorch_kaldi_resnet_amd import tiling
+    from test_pairs_gpu import encode_pairs, sigma_of
+    old = (ops.SPLIT, ops.PIPE_CONV, ops.WS_CONV, ops.PIPE_M16, ops.PROFILE)
+    ops.SPLIT, ops.WS_CONV, ops.PIPE_CONV = 3, "0", True
+    real_tile = tiling.conv_tile
+    tiling.conv_tile = lambda *key, mode=0, split=0: (tile[0], tile[1], 3, 2)
+    try:
+        torch.manual_seed(3)
+        x = torch.randn(B, H, Wd, Cin, device="cuda")
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+        wpk, wpk_t = ops.pack_conv_weight(w), ops.pack_conv_weight(w, True)
+        sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+        e2 = torch.rand(2, Cout, device="cuda") + 0.5
+        dy = torch.randn(B, H, Wd, Cout, device="cuda") * 1e-3
+        res_in = torch.randn(B, H, Wd, Cout, device="cuda")
+        dadd = torch.randn(B, H, Wd, Cin, device="cuda") * 1e-3
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        m2 = torch.randint(-2 ** 31, 2 ** 31 - 1, (B * H * Wd * (Cin // 32),), device="cuda", dtype=torch.int32, generator=g)
+        raw_p = torch.randn(B, H, Wd, Cin, device="cuda")
+        bn4 = torch.stack([torch.randn(Cin, device="cuda") * 0.1, torch.rand(Cin, device="cuda") + 0.5,
+                           torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1])
+        slot = ops.absmax_into(dy, torch.zeros(1, device="cuda", dtype=torch.int32))
+        dy_pairs = encode_pairs(dy.cpu(), sigma_of(slot)).cuda()
+        res, labels = {}, {}
+        for m16 in (False, True):
+            ops.PIPE_M16 = m16
+            ops.PROFILE = []
+            out, st = ops.conv_fwd(x, wpk, Cout, 3, 1, in_affine=(sc, sh), stats=True)
+            out2, _ = ops.conv_fwd(x, wpk, Cout, 3, 1, epi_affine=(e2[0], e2[1]), epi_add=res_in, relu=True)
+            dx = ops.conv_dgrad(dy, wpk_t, Cin, 3, 1, (H, Wd), add=dadd)
+            dxp, part = ops.conv_dgrad(dy_pairs, wpk_t, Cin, 3, 1, (H, Wd), add=dadd, add_mask=m2, bn_bwd=(raw_p, None, bn4, m2),
+                                       in_amax=slot, in_presplit=True)
+            torch.cuda.synchronize()
+            labels[m16] = [p[0] for p in ops.PROFILE if p[0].startswith("conv_")]
+            ops.PROFILE = None
+            res[m16] = (out, st.double().sum(0), out2, dx, dxp, part.double().sum(0))
+        assert labels[True] == ["conv_pipe_kernel<3,2,false,false,false,true>"] * 3 + ["conv_pipe_kernel<3,2,false,false,true,true>"], labels[True]
+        assert labels[False] == ["conv_pipe_kernel<3,2,false,false>"] * 3 + ["conv_pipe_kernel<3,2,false,false,true>"], labels[False]
+        for i, (u, v) in enumerate(zip(res[False], res[True])):
+            tol = (2e-6 if i not in (1, 5) else 2e-5) * float(u.abs().max())       # (statistics: sums over all pixels)
+            assert float((u.double() - v.double()).abs().max()) <= tol, (i, float((u.double() - v.double()).abs().max()), tol)
+        ref = torch.nn.functional.conv2d(torch.relu(x * sc + sh).permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1)
+        errs = [float((res[k][0].permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()) for k in (False, True)]
+        assert errs[1] < 1e-6 and errs[1] < 1.5 * errs[0] + 1e-8, errs
+        gref = torch.nn.grad.conv2d_input((B, Cin, H, Wd), w.double().cpu(), dy.permute(0, 3, 1, 2).double().cpu(), padding=1)
+        gerr = [float((res[k][3].permute(0, 3, 1, 2).double().cpu() - dadd.permute(0, 3, 1, 2).double().cpu() - gref).norm() / gref.norm()) for k in (False, True)]
+        assert gerr[1] < 1e-6 and gerr[1] < 1.5 * gerr[0] + 1e-8, gerr
+    finally:
+        ops.SPLIT, ops.PIPE_CONV, ops.WS_CONV, ops.PIPE_M16, ops.PROFILE = old
+        tiling.conv_tile = real_tile
+
+
 def test_bn_apply_sign_mask(ops):
     """spk_bn_apply's optional 1-bit output: bit k of word j of a pixel = (out[pixel][32 j + k] > 0)."""
     torch.manual_seed(1)
