@@ -86,9 +86,11 @@ struct ConvArgs {
 // that follows an MFMA in the same instruction stream does; staging done as a separate phase - or by separate producer
 // waves - is therefore paid in full on top of the matrix time.
 #define PIPE_D 3
-#ifndef PIPE16_VPM
-#define PIPE16_VPM 2    // the same for the 16x16x32 form: its matrix instruction leaves 8 of its 16 cycles to the vector issue
-#endif
+#ifndef PIPE16_D
+#define PIPE16_D 3      // staging items in flight in the 16x16x32 form (an item is consumed PIPE16_D half steps after its load;
+#endif                  // 4 / 5 / 6 spill at the 256-register bound and measured slower)
+// (M16_NO_STAGE / M16_NO_FINISH / M16_NO_ISSUE: diagnostic builds of the 16x16x32 form without the in-loop staging / without its
+//  conversion + LDS write / without its global loads - wrong results by construction; profiles/r03_m16_ablation.log)
 #ifndef PIPE_VPM
 #define PIPE_VPM 6      // VALU instructions scheduled behind every MFMA of a pipelined tap (2 / 4 / 6 / 8 measured: 57.08 / 57.29 / 56.94 / 56.9 ms per step)
 #endif
@@ -376,7 +378,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         bool more = false;
         f32x4 scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
         unsigned inbm = 0;
-        f32x4 pre[PIPE_D];
+        f32x4 pre[PIPE16_D];
         auto phase = [&](int chunk, int slot) {
             more = chunk < nchunks;
             cn = (more ? chunk : nchunks - 1) * CK + quad * 4;
@@ -400,7 +402,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
             inbm = (inbm & ~(1u << u)) | ((unsigned)ok << u);
             const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
-            pre[u % PIPE_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+            pre[u % PIPE16_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
         };
         auto finish = [&](auto uc) {                                 // transform + fp16 split + LDS write of item u (branch-free)
             constexpr int u = decltype(uc)::value;
@@ -410,11 +412,11 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const bool ok = (inbm >> u) & 1u;
             const bool real = more & (p < halo_pix);
             if constexpr (PRE) {
-                const uint4 bb = __builtin_bit_cast(uint4, pre[u % PIPE_D]);
+                const uint4 bb = __builtin_bit_cast(uint4, pre[u % PIPE16_D]);
                 const uint2 t0 = {ok ? bb.x : 0u, ok ? bb.y : 0u}, t1 = {ok ? bb.z : 0u, ok ? bb.w : 0u};
                 store_pair(real ? nxt : dump, real ? p : 0, t0, t1);
             } else {
-                f32x4 w = pre[u % PIPE_D] * scn + shn;
+                f32x4 w = pre[u % PIPE16_D] * scn + shn;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
                 store_px(real ? nxt : dump, real ? p : 0, w);
@@ -441,7 +443,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         };
 #define IC(n) std::integral_constant<int, n>{}
         // One scheduling region per half step: MT * AN * 3 matrix instructions, the A fragments one row tile ahead, in the first
-        // half the B fragments of the next step, and one staging item (finish fin, issue fin + PIPE_D).  roll: after the last row
+        // half the B fragments of the next step, and one staging item (finish fin, issue fin + PIPE16_D).  roll: after the last row
         // tile of the step, read row tile 0 of the next step (not across a barrier that completes the slot it reads).
         auto hstep = [&](auto half_c, auto fin_c, auto roll_c, const f32x4 (*bc)[AN], f32x4 (*bn)[AN], int w_next, int o_cur, int o_next) {
             constexpr int half = decltype(half_c)::value, fin = decltype(fin_c)::value;
@@ -451,7 +453,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                 // One scheduling region per row tile: its AN * 3 matrix instructions in source order (four independent
                 // accumulators in rotation - a dependent 16x16x32 issued back to back waits for its predecessor), the A fragments
                 // of the NEXT row tile read first, and one piece of the other work: the B fragments of the next step + the global
-                // conversion and LDS write of a staging item (tile 0), the global load of the item PIPE_D later (tile 1).
+                // conversion and LDS write of a staging item (tile 0), the global load of the item PIPE16_D later (tile 1).
                 const int i16 = half * MT + ii;
                 __builtin_amdgcn_sched_barrier(0);
                 if (i16 + 1 < 2 * MT) load_a(aq[(i16 + 1) & 1], i16 + 1, o_cur);
@@ -460,12 +462,16 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                 if (ii == 0) {
                     if constexpr (half == 0) load_b(bn, w_next);
 #ifndef M16_NO_STAGE
-                    if constexpr (fin >= 0) finish(IC(fin));              // (reads pre[fin % PIPE_D] before issue below refills it)
+#ifndef M16_NO_FINISH
+                    if constexpr (fin >= 0) finish(IC(fin));              // (reads pre[fin % PIPE16_D] before issue below refills it)
+#endif
 #endif
                 }
 #ifndef M16_NO_STAGE
                 if (ii == 1 % MT) {
-                    if constexpr (fin >= 0) issue(IC(fin + PIPE_D));
+#ifndef M16_NO_ISSUE
+                    if constexpr (fin >= 0) issue(IC(fin + PIPE16_D));
+#endif
                 }
 #endif
 #pragma unroll
@@ -481,15 +487,6 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             __builtin_amdgcn_sched_barrier(0x7F7);      // everything but a matrix instruction may cross
                         }
                     }
-#ifdef M16_GROUPS
-                __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);              // the A fragments of the next row tile first
-#pragma unroll
-                for (int k = 0; k < AN * 3; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA (16 cycles, 8 of them hold the vector issue)
-                    __builtin_amdgcn_sched_group_barrier(0x002, PIPE16_VPM, 0);     // VALU instructions in its shadow
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // (an LDS write of the item when one is ready)
-                }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         };

@@ -141,7 +141,7 @@ WS_AUTO_MIN_COUT = 128
 # in-wave pipelined staging (conv_pipe_kernel): on by default for the f16x3 3x3 launches it covers; SPK_CONV_PIPE=0 disables
 PIPE_CONV = os.environ.get("SPK_CONV_PIPE", "1") == "1"
 # its v_mfma_f32_16x16x32_f16 form (two taps per K step; the chip holds a higher clock on that instruction shape)
-PIPE_M16 = os.environ.get("SPK_PIPE_M16", "0") == "1"
+PIPE_M16 = os.environ.get("SPK_PIPE_M16", "1") == "1"
 # the same for the 3x3 weight gradients (conv_wgrad_pipe_kernel): opt-in.  Bit-identical, but no faster than
 # conv_wgrad_split_kernel (+2..6 % on the 32/64-channel layers, -1..-12 % elsewhere, profiles/r02_wgrad_ablation.log): a tap of
 # the weight gradient has three matrix instructions against ~60 VALU instructions of a staging item, so the VALU stream sets the
