@@ -163,10 +163,11 @@ if _os.environ.get("SPK_FUSED_TILE"):
 
 
 # ... and SPK_PLAIN_TILE="OH,OW,ntaps,Cout:TH,TW,MT,NT" the tile of the plain launches of a shape (any stride)
-_PLAIN_TILE_OVERRIDE = None
-if _os.environ.get("SPK_PLAIN_TILE"):
-    _k, _v = _os.environ["SPK_PLAIN_TILE"].split(":")
-    _PLAIN_TILE_OVERRIDE = (tuple(int(x) for x in _k.split(",")), tuple(int(x) for x in _v.split(",")))
+# (several shapes: entries separated by ';')
+_PLAIN_TILE_OVERRIDE = {}
+for _e in filter(None, _os.environ.get("SPK_PLAIN_TILE", "").split(";")):
+    _k, _v = _e.split(":")
+    _PLAIN_TILE_OVERRIDE[tuple(int(x) for x in _k.split(","))] = tuple(int(x) for x in _v.split(","))
 
 
 def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
@@ -176,8 +177,8 @@ def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     key = (OH, OW, IS, kspan_y, kspan_x, ntaps, Cout)
     if mode and _FUSED_TILE_OVERRIDE and key == _FUSED_TILE_OVERRIDE[0]:
         return _FUSED_TILE_OVERRIDE[1]
-    if not mode and _PLAIN_TILE_OVERRIDE and (OH, OW, ntaps, Cout) == _PLAIN_TILE_OVERRIDE[0]:
-        return _PLAIN_TILE_OVERRIDE[1]
+    if not mode and (OH, OW, ntaps, Cout) in _PLAIN_TILE_OVERRIDE:
+        return _PLAIN_TILE_OVERRIDE[(OH, OW, ntaps, Cout)]
     if split:
         if mode and key + (mode,) in FORCE_CONV_SPLIT:
             return FORCE_CONV_SPLIT[key + (mode,)]
