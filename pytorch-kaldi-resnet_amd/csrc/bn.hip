@@ -213,10 +213,48 @@ extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 // ---- apply: out = [relu]( raw*scale + shift [+ res | + res*rscale + rshift] ) -----------------------
-#ifndef BN_STREAM_U
-#define BN_STREAM_U 1      // 16-byte groups in flight per thread and input stream in the streaming kernels below (2 and 4 measured:
-                           // 54.45 / 54.50 ms per step against 54.34 - these passes already run at the achievable HBM rate)
+// 16-byte groups per thread and input stream in the two apply kernels, and their grids (CAP 0: exactly enough blocks to cover the
+// tensor once, no grid-stride loop; > 0: that many persistent blocks at most) - each pair measured inside the training step
+// (profiles/r03_ab_runs.log).  tools/probe/stream_probe.hip: three 786 MB tensors stream at 5.8-6.05 TB/s from a covering grid and
+// at 4.5-5.0 TB/s from 2048 / 8192 persistent blocks - but a covering grid repeats the per-thread work (per-channel vectors, the
+// absmax commit) for every group, so it pays only with several groups per thread.
+#ifndef BN_APPLY_U
+#define BN_APPLY_U 4
 #endif
+#ifndef BN_APPLY_CAP
+#define BN_APPLY_CAP 0
+#endif
+#ifndef BN_BWD_APPLY_U
+#define BN_BWD_APPLY_U 1
+#endif
+#ifndef BN_BWD_APPLY_CAP
+#define BN_BWD_APPLY_CAP 8192
+#endif
+static int stream_grid(long long nquads, int per_thread = 1, int cap = 8192) {
+    long long nb = (nquads + 256LL * per_thread - 1) / (256LL * per_thread);
+    if (cap > 0 && nb > cap) nb = cap;
+    if (nb > 2147483647LL) nb = 2147483647LL;
+    return (int)(nb < 1 ? 1 : nb);
+}
+// BN_NT: non-temporal loads / stores of the streamed tensors (the probe: 6.48 against 6.05 TB/s in isolation; in the step
+// bn_apply 3.31 -> 3.04 ms, bn_bwd_apply 4.64 -> 4.25 ms over their launches)
+#ifndef BN_NT
+#define BN_NT 1
+#endif
+static __device__ __forceinline__ f32x4 ld_stream(const float* p) {
+#if BN_NT
+    return __builtin_nontemporal_load((const f32x4*)p);
+#else
+    return *(const f32x4*)p;
+#endif
+}
+static __device__ __forceinline__ void st_stream(float* p, f32x4 v) {
+#if BN_NT
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+    *(f32x4*)p = v;
+#endif
+}
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -224,8 +262,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int C, int relu, unsigned* __restrict__ amax_out) {
     const int cmask = C - 1;
     float mx = 0.f;
-    constexpr int U = BN_STREAM_U;
+    constexpr int U = BN_APPLY_U;
     const long long stride = (long long)gridDim.x * 256;
+    // C <= 1024 (a power of two): a block covers 1024 floats and the stride is whole blocks - a thread stays on the channels of
+    // its first group, and the per-channel vectors are loaded once
+    const bool fixed_c = C <= 1024;
+    const int c0 = (threadIdx.x * 4) & cmask;
+    f32x4 psc = *(const f32x4*)(scale + c0), psh = *(const f32x4*)(shift + c0), prs = psc, prh = psh;
+    if (rscale) {
+        prs = *(const f32x4*)(rscale + c0);
+        prh = *(const f32x4*)(rshift + c0);
+    }
     for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nquads; i0 += stride * U) {
         // U independent groups per thread: all their loads are issued before the first use (a group past the end re-reads
         // group i0 and is dropped) - more bytes in flight per CU on these HBM-bound streams
@@ -235,18 +282,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + stride * u;
             idx[u] = i < nquads ? i : i0;
-            rv[u] = *(const f32x4*)(raw + idx[u] * 4);
-            if (res) sv[u] = *(const f32x4*)(res + idx[u] * 4);
+            rv[u] = ld_stream(raw + idx[u] * 4);
+            if (res) sv[u] = ld_stream(res + idx[u] * 4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + stride * u;
             if (i >= nquads) continue;
-            const int c = (int)((i * 4) & cmask);
-            f32x4 v = rv[u] * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+            if (!fixed_c) {
+                const int c = (int)((i * 4) & cmask);
+                psc = *(const f32x4*)(scale + c);
+                psh = *(const f32x4*)(shift + c);
+                if (rscale) {
+                    prs = *(const f32x4*)(rscale + c);
+                    prh = *(const f32x4*)(rshift + c);
+                }
+            }
+            f32x4 v = rv[u] * psc + psh;
             if (res) {
                 f32x4 r = sv[u];
-                if (rscale) r = r * *(const f32x4*)(rscale + c) + *(const f32x4*)(rshift + c);
+                if (rscale) r = r * prs + prh;
                 v += r;
             }
             if (relu) {
@@ -255,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                 v[2] = fmaxf(v[2], 0.f);
                 v[3] = fmaxf(v[3], 0.f);
             }
-            *(f32x4*)(out + i * 4) = v;
+            st_stream(out + i * 4, v);
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             if (mask_out) {
                 // sign mask of the output, one bit per value, 32 channels per word: the backward pass reads these bits instead
@@ -273,12 +328,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (amax_out) spk_wave_amax_commit(mx, amax_out);     // absmax(out): the operand scale of its f16x3 consumers
 }
 
-static int stream_grid(long long nquads) {
-    long long nb = (nquads + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    return (int)(nb < 1 ? 1 : nb);
-}
-
 extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* shift, const float* res,
                             const float* res_scale, const float* res_shift, float* out, unsigned* mask_out, long long N, int C,
                             int relu, unsigned* amax_out, void* stream) {
@@ -288,7 +337,7 @@ extern "C" int spk_bn_apply(const float* raw, const float* scale, const float* s
     SPK_REQUIRE(!res_scale || res, "spk_bn_apply: residual affine without residual");
     SPK_REQUIRE(!mask_out || C % 32 == 0, "spk_bn_apply: the sign mask needs C %% 32 == 0 (C=%d)", C);
     const long long nquads = N * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nquads, BN_APPLY_U, BN_APPLY_CAP)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res,
                        res_scale, res_shift, out, mask_out, nquads, C, relu, amax_out);
     SPK_LAUNCH_CHECK("spk_bn_apply");
     return 0;
@@ -335,8 +384,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     for (long long r = r0 + prow; r < r1; r += rstep) {
         const long long off = r * C + quad * 4;
-        const f32x4 rv = *(const f32x4*)(raw + off);
-        f32x4 d = *(const f32x4*)(dy + off);
+        const f32x4 rv = ld_stream(raw + off);
+        f32x4 d = ld_stream(dy + off);
         d = bn_mask(d, mode, act, raw, rv, sc, sh, off, C);
         const f32x4 xh = (rv - mu) * is;
         s += d;
@@ -459,9 +508,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int cmask = C - 1;
     float mx = 0.f;
     const float sig = pair_scale ? spk_sigma_from_amax_bits(*pair_scale) : 1.f;
-    constexpr int U = BN_STREAM_U;
+    constexpr int U = BN_BWD_APPLY_U;
     const long long stride = (long long)gridDim.x * 256;
     const int lg = 31 - __builtin_clz((unsigned)C);          // C is a power of two
+    // (C <= 1024: a thread stays on the channels of its first group - see bn_apply_kernel - the seven per-channel vectors once)
+    const bool fixed_c = C <= 1024;
+    const int c0 = (threadIdx.x * 4) & cmask;
+    f32x4 pmu = *(const f32x4*)(mean + c0), pis = *(const f32x4*)(invstd + c0), pk1 = *(const f32x4*)(coef + c0);
+    f32x4 pm1 = *(const f32x4*)(coef + C + c0), pm2 = *(const f32x4*)(coef + 2 * C + c0), psc = pmu, psh = pmu;
+    if (mode == MASK_RAW) {
+        psc = *(const f32x4*)(scale + c0);
+        psh = *(const f32x4*)(shift + c0);
+    }
     for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nquads; i0 += stride * U) {
         f32x4 rvv[U], dv[U], av[U];
         unsigned mw[U];
@@ -471,8 +529,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const long long i = i0 + stride * u;
             idx[u] = i < nquads ? i : i0;
             const long long off = idx[u] * 4;
-            rvv[u] = *(const f32x4*)(raw + off);
-            dv[u] = *(const f32x4*)(dy + off);
+            rvv[u] = ld_stream(raw + off);
+            dv[u] = ld_stream(dy + off);
             if (mode == MASK_BITS) mw[u] = ((const unsigned*)act)[(off >> lg) * (C >> 5) + ((int)(off & cmask) >> 5)];
             else if (mode == MASK_ACT) av[u] = *(const f32x4*)(act + off);
         }
@@ -480,7 +538,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int u = 0; u < U; ++u) {
             const long long i = i0 + stride * u;
             if (i >= nquads) continue;
-            const int c = (int)((i * 4) & cmask);
+            const int c = fixed_c ? c0 : (int)((i * 4) & cmask);
+            if (!fixed_c) {
+                pmu = *(const f32x4*)(mean + c);
+                pis = *(const f32x4*)(invstd + c);
+                pk1 = *(const f32x4*)(coef + c);
+                pm1 = *(const f32x4*)(coef + C + c);
+                pm2 = *(const f32x4*)(coef + 2 * C + c);
+                if (mode == MASK_RAW) {
+                    psc = *(const f32x4*)(scale + c);
+                    psh = *(const f32x4*)(shift + c);
+                }
+            }
             const long long off = i * 4;
             const f32x4 rv = rvv[u];
             f32x4 d = dv[u];
@@ -492,20 +561,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
                 for (int k = 0; k < 4; ++k) d[k] = av[u][k] > 0.f ? d[k] : 0.f;
             } else if (mode == MASK_RAW) {
-                const f32x4 z = rv * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+                const f32x4 z = rv * psc + psh;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) d[k] = z[k] > 0.f ? d[k] : 0.f;
             }
-            const f32x4 xh = (rv - *(const f32x4*)(mean + c)) * *(const f32x4*)(invstd + c);
-            const f32x4 k1 = *(const f32x4*)(coef + c), m1 = *(const f32x4*)(coef + C + c), m2 = *(const f32x4*)(coef + 2 * C + c);
-            const f32x4 o = k1 * (d - m1 - xh * m2);
-            if (dz_out) *(f32x4*)(dz_out + off) = d;
+            const f32x4 xh = (rv - pmu) * pis;
+            const f32x4 o = pk1 * (d - pm1 - xh * pm2);
+            if (dz_out) st_stream(dz_out + off, d);
             if (pair_scale) {      // f16 pair tensor: converted here once, staged by plain copy in the data and weight gradients
                 uint2 t0, t1;
                 split2h(o, sig, t0, t1);
-                *(f32x4*)(draw + off) = spk_pair_pack(t0, t1);
+                st_stream(draw + off, spk_pair_pack(t0, t1));
             } else
-                *(f32x4*)(draw + off) = o;
+                st_stream(draw + off, o);
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         }
     }
@@ -520,7 +588,7 @@ extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* 
     SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
     SPK_REQUIRE((mask_mode != MASK_ACT && mask_mode != MASK_BITS) || act, "spk_bn_bwd_apply: MASK_ACT / MASK_BITS need the activated tensor / its sign bits");
     const long long nquads = N * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads, BN_BWD_APPLY_U, BN_BWD_APPLY_CAP)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
                        invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out, pair_scale);
     SPK_LAUNCH_CHECK("spk_bn_bwd_apply");
     return 0;

@@ -5,6 +5,20 @@
 #ifndef STAGE_U
 #define STAGE_U 4   // staging loads in flight per thread
 #endif
+// CONV_NT bit 0: non-temporal stores of the convolution output and side outputs; bit 1: non-temporal loads of the epilogue's read
+// streams (shortcut, raw tensor of the BatchNorm-backward statistics); bit 2: of the fused BatchNorm-backward staging streams
+#ifndef CONV_NT
+#define CONV_NT 3
+#endif
+static __device__ __forceinline__ void conv_st(float* p, f32x4 v) {
+    if constexpr ((CONV_NT & 1) != 0) __builtin_nontemporal_store(v, (f32x4*)p);
+    else *(f32x4*)p = v;
+}
+template <int BIT>
+static __device__ __forceinline__ f32x4 conv_ld(const float* p) {
+    if constexpr ((CONV_NT & BIT) != 0) return __builtin_nontemporal_load((const f32x4*)p);
+    else return *(const f32x4*)p;
+}
 #ifndef STAGE_U2
 #define STAGE_U2 2  // pixels in flight per thread in the fused BatchNorm-backward staging (three loads each)
 #endif
@@ -270,8 +284,8 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         core[u] = inb[u] && iy >= oy0 && iy < oy0 + a.TH && ix >= ox0 && ix < ox0 + a.TW;
                         const unsigned pi = inb[u] ? (unsigned)(iy * a.IW + ix) : pi_safe;      // pixel inside image b
                         off[u] = pi * (unsigned)a.Cin + (unsigned)c;
-                        v[u] = *(const f32x4*)(img_in + off[u]);
-                        rw[u] = *(const f32x4*)(img_raw + off[u]);
+                        v[u] = conv_ld<4>(img_in + off[u]);
+                        rw[u] = conv_ld<4>(img_raw + off[u]);
                         if (a.in_mask) mw[u] = img_mask[pi * (unsigned)(a.Cin >> 5) + (unsigned)(c >> 5)];
                         else if (a.in_act) ac[u] = *(const f32x4*)(img_act + off[u]);
                     }
@@ -301,8 +315,8 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             } else
                                 store_px(ldsp, p, w);
                             if (owner && core[u]) {
-                                *(f32x4*)(img_draw + off[u]) = side;
-                                if (a.side_dz) *(f32x4*)(img_dz + off[u]) = dz;
+                                conv_st(img_draw + off[u], side);
+                                if (a.side_dz) conv_st(img_dz + off[u], dz);
                                 side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                             }
                         }
@@ -1043,7 +1057,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         v[2] = fmaxf(v[2], 0.f);
                         v[3] = fmaxf(v[3], 0.f);
                     }
-                    *(f32x4*)dst = v;
+                    conv_st(dst, v);
                     out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                     if (flags & SPK_EPI_BNBWD) {
                         // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so
@@ -1109,7 +1123,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             v[2] = fmaxf(v[2], 0.f);
                             v[3] = fmaxf(v[3], 0.f);
                         }
-                        *(f32x4*)(a.out + ob + qc * 4) = v;
+                        conv_st(a.out + ob + qc * 4, v);
                         out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         ssum += v;
                         ssq += v * v;
@@ -1131,11 +1145,11 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     const int pix = ob >= 0 ? px : pix_safe;
                     const int o = pix * a.Cout + ch0;                                     // element offset of this lane's quad
                     if (f_add) {
-                        adv[kk] = *(const f32x4*)(a.epi_add + o);
+                        adv[kk] = conv_ld<2>(a.epi_add + o);
                         if (a.add_mask) amw[kk] = a.add_mask[(size_t)pix * cw32 + (ch0 >> 5)];
                     }
                     if (f_bnb) {
-                        rwv[kk] = *(const f32x4*)(a.bn_raw + o);
+                        rwv[kk] = conv_ld<2>(a.bn_raw + o);
                         if (a.bn_mask) bmw[kk] = a.bn_mask[(size_t)pix * cw32 + (ch0 >> 5)];
                     }
                 }
@@ -1167,7 +1181,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             v[2] = fmaxf(v[2], 0.f);
                             v[3] = fmaxf(v[3], 0.f);
                         }
-                        *(f32x4*)dst = v;
+                        conv_st(dst, v);
                         out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         if (f_bnb) {
                             // v is the gradient wrt a BatchNorm(+ReLU) output: accumulate (sum dz, sum dz*xhat) of that BN so

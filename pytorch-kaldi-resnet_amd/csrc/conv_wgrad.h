@@ -28,3 +28,12 @@ struct WgradArgs {
     const unsigned* x_amax;    //   same for the X operand (absmax of the STAGED values - after a fused BatchNorm+ReLU - or a bound)
 };
 
+// WGRAD_NT bit 0: non-temporal loads of dY, bit 1: of X, in the weight-gradient kernels (A/B builds; default off)
+#ifndef WGRAD_NT
+#define WGRAD_NT 0
+#endif
+template <int BIT>
+static __device__ __forceinline__ f32x4 wgrad_ld(const void* p) {
+    if constexpr ((WGRAD_NT & BIT) != 0) return __builtin_nontemporal_load((const f32x4*)p);
+    else return *(const f32x4*)p;
+}

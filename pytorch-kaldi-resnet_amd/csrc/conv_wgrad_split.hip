@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
 #ifdef WG_ABL_NO_PREFETCH
             px[u] = (f32x4){(float)off, 0.f, 1.f, 2.f};
 #else
-            px[u] = *(const f32x4*)(xb + off);
+            px[u] = wgrad_ld<2>(xb + off);
 #endif
         }
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
 #ifdef WG_ABL_NO_PREFETCH
             pd[u] = (f32x4){(float)off, 0.f, 1.f, 2.f};
 #else
-            pd[u] = *(const f32x4*)(db + off);
+            pd[u] = wgrad_ld<1>(db + off);
 #endif
         }
     };
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
                 const int iy = iy0 + hy, ix = ix0 + hx;
                 if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) inx |= 1u << u;
                 const int cy = min(max(iy, 0), a.IH - 1), cx = min(max(ix, 0), a.IW - 1);
-                px[u] = *(const f32x4*)(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
+                px[u] = wgrad_ld<2>(a.x + (size_t)((b * a.IH + cy) * a.IW + cx) * a.Cin + ci0 + quad * 4);
             }
 #pragma unroll
             for (int u = 0; u < ND; ++u) {
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ws_kernel(WgradArgs a) {
                 const int oy = oy0 + ly, ox = ox0 + lx;
                 if (p0 < npix && oy < a.OH && ox < a.OW) ind |= 1u << u;
                 const int cy = min(oy, a.OH - 1), cx = min(ox, a.OW - 1);
-                pd[u] = *(const f32x4*)(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
+                pd[u] = wgrad_ld<1>(a.dy + (size_t)((b * a.OH + cy) * a.OW + cx) * a.Cout + co0 + cq * 4);
             }
         };
         auto publish = [&](const f32x4 (&px)[NX], const f32x4 (&pd)[ND], unsigned inx, unsigned ind, unsigned char* xs) {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
             const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW && p < halo_pix;
             if (ok) inx |= 1u << u;
             const unsigned off = ok ? (unsigned)iy * x_row + (unsigned)ix * x_px + x_c : x_safe;
-            px[u] = *(const f32x4*)(xb + off);
+            px[u] = wgrad_ld<2>(xb + off);
         }
 #pragma unroll
         for (int u = 0; u < WM_ND; ++u) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
             const bool ok = p < npix && oy < a.OH && ox < a.OW;
             if (ok) ind |= 1u << u;
             const unsigned off = ok ? (unsigned)oy * d_row + (unsigned)ox * d_px + d_c : d_safe;
-            pd[u] = *(const f32x4*)(db + off);
+            pd[u] = wgrad_ld<1>(db + off);
         }
     };
     auto publish = [&]() {
