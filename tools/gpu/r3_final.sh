@@ -2,7 +2,7 @@
 # round-3 evidence run: rocprofv3 kernel trace + FETCH / WRITE passes + SQ counters of the default bench command, then the
 # bench lines themselves (default with CPU baseline + EER, --ingest, c4, c5, two-rank rehearsal on one GPU)
 set -o pipefail
-D=gpurun_out/r3z
+D=gpurun_out/r3final
 mkdir -p $D
 run() {
     local name=$1 to=$2; shift 2
@@ -22,4 +22,5 @@ run bench_ingest 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --
 run bench_c4 400 python3 bench.py --config c4 --steps 16 --warmup 8 --no-cpu-baseline --no-eer
 run bench_c5 300 python3 bench.py --config c5 --steps 20 --warmup 5
 SPK_FORCE_DEVICE=0 SPK_DIST_BACKEND=gloo run bench_gpus2_rehearsal 300 python3 bench.py --gpus 2 --batch 64 --steps 5 --warmup 2 --no-cpu-baseline --no-eer --no-roofline --no-f16-window
+run smoke 200 python3 __graft_entry__.py smoke
 du -sh $D; cat $D/progress.log
