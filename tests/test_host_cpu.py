@@ -32,6 +32,28 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert rc < 0 and b"spk_sgd_step" in lib.spk_last_error()
 
 
+def test_flag_constants_agree_between_header_binding_and_kernels():
+    """The launch flags live in three places - include/spkhip.h (#define), csrc/spk_common.h (enum) and hip.py (constants): every
+    flag the header defines must have the same value in the other two."""
+    def value(expr):
+        expr = expr.split("/*")[0].strip().rstrip(",")
+        assert re.fullmatch(r"[0-9()< ]+", expr), expr
+        return eval(expr)
+    hdr = open(os.path.join(ROOT, "include", "spkhip.h")).read()
+    defines = {m.group(1): value(m.group(2)) for m in re.finditer(r"^#define (SPK_[A-Z0-9_]+)[ \t]+(\(?[0-9][0-9 <()]*)", hdr, re.M)}
+    common = open(os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "csrc", "spk_common.h")).read()
+    enum = {m.group(1): value(m.group(2)) for m in re.finditer(r"^\s+(SPK_[A-Z0-9_]+) = ([0-9][0-9 <]*),?", common, re.M)}
+    flags = {k: v for k, v in defines.items() if k in enum}
+    assert len(flags) >= 12, sorted(flags)
+    for name, v in flags.items():
+        assert enum[name] == v, (name, enum[name], v)
+        short = name[4:]
+        if hasattr(hip, short):
+            assert getattr(hip, short) == v, (name, getattr(hip, short), v)
+    for short in ("CONV_PIPE", "CONV_M16", "IN_PRESPLIT", "SIDE_PRESPLIT", "DY_PRESPLIT", "IN_BNBWD", "EPI_BNBWD"):
+        assert "SPK_" + short in flags and hasattr(hip, short), short
+
+
 def test_kaldi_io_reads_reference_written_ark(gold_dir):
     d = os.path.join(gold_dir, "io")
     exp = np.load(os.path.join(d, "feats_expected.npz"))
