@@ -399,10 +399,11 @@ class Engine:
         main = torch.cuda.current_stream()
         side = self.wgrad_stream
         side.wait_stream(main)                      # dy / x are produced on the main stream
-        if not torch.cuda.is_current_stream_capturing():
-            for t in (x, dy):
-                t.record_stream(side)               # keep the allocator from recycling them under the side kernel
-        # (inside a graph capture the private pool keeps every tensor of the captured region alive)
+        # keep the allocator from recycling them under the side kernel - ALSO inside a graph capture: a block freed during the
+        # capture goes back to the graph's private pool and is handed to the next allocation on the main branch, while the side
+        # branch may replay later (measured: SPK_GRAPH_SIDE=1 without this gave a different loss on every run)
+        for t in (x, dy):
+            t.record_stream(side)
         with torch.cuda.stream(side):
             ops.conv_wgrad(x, dy, dw, k, stride, in_affine=in_affine, accumulate=accumulate, dy_amax=dy_amax, x_amax=x_amax,
                            dy_presplit=dy_presplit)
@@ -621,8 +622,9 @@ class GraphedTrainStep:
         m = engine.m
         dev = m.flat_parameters().device
         self.eng = engine
-        # measured on MI355X / ROCm 7.2: a captured two-branch graph (weight gradients on the side stream) replays
-        # ~2 % slower than the same kernels captured on one stream, so the graph is recorded single-stream
+        # measured on MI355X / ROCm 7.2: a captured two-branch graph (weight gradients on the side stream) replays no faster than the
+        # same kernels captured on one stream (round 1: ~2 % slower; round 3: 52.5-52.8 ms both ways), so the graph is recorded
+        # single-stream
         side, engine.use_side_stream = engine.use_side_stream, bool(side_stream)
         self.x = torch.zeros(batch, m.feat_dim, frames, device=dev)
         self.y = torch.zeros(batch, dtype=torch.long, device=dev)
