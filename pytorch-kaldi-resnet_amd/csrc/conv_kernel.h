@@ -101,8 +101,11 @@ struct ConvArgs {
 // waves - is therefore paid in full on top of the matrix time.
 #define PIPE_D 3
 #ifndef PIPE16_D
-#define PIPE16_D 3      // staging items in flight in the 16x16x32 form (an item is consumed PIPE16_D half steps after its load;
-#endif                  // 4 / 5 / 6 spill at the 256-register bound and measured slower)
+#define PIPE16_D 3      // staging items in flight in the 16x16x32 form, pair input (an item is consumed PIPE16_D half steps after
+#endif                  // its load; 4 and 5 measured equal: 51.18-51.28 / 51.20 against 51.02-51.21 ms per step)
+#ifndef PIPE16_D_CONV
+#define PIPE16_D_CONV 3 // the same for the form that converts while staging (fp32 input); 4 is slower (51.7 ms: registers)
+#endif
 // (M16_NO_STAGE / M16_NO_FINISH / M16_NO_ISSUE: diagnostic builds of the 16x16x32 form without the in-loop staging / without its
 //  conversion + LDS write / without its global loads - wrong results by construction; profiles/r03_m16_ablation.log)
 #ifndef PIPE_VPM
@@ -392,7 +395,9 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         bool more = false;
         f32x4 scn = {1.f, 1.f, 1.f, 1.f}, shn = {0.f, 0.f, 0.f, 0.f};
         unsigned inbm = 0;
-        f32x4 pre[PIPE16_D];
+        // staging items in flight: an item is consumed D16 half steps after its load
+        constexpr int D16 = PRE ? PIPE16_D : PIPE16_D_CONV;
+        f32x4 pre[D16];
         auto phase = [&](int chunk, int slot) {
             more = chunk < nchunks;
             cn = (more ? chunk : nchunks - 1) * CK + quad * 4;
@@ -416,7 +421,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
             inbm = (inbm & ~(1u << u)) | ((unsigned)ok << u);
             const unsigned pi = ok ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
-            pre[u % PIPE16_D] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
+            pre[u % D16] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)cn);
         };
         auto finish = [&](auto uc) {                                 // transform + fp16 split + LDS write of item u (branch-free)
             constexpr int u = decltype(uc)::value;
@@ -426,16 +431,25 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const bool ok = (inbm >> u) & 1u;
             const bool real = more & (p < halo_pix);
             if constexpr (PRE) {
-                const uint4 bb = __builtin_bit_cast(uint4, pre[u % PIPE16_D]);
+                const uint4 bb = __builtin_bit_cast(uint4, pre[u % D16]);
                 const uint2 t0 = {ok ? bb.x : 0u, ok ? bb.y : 0u}, t1 = {ok ? bb.z : 0u, ok ? bb.w : 0u};
                 store_pair(real ? nxt : dump, real ? p : 0, t0, t1);
             } else {
-                f32x4 w = pre[u % PIPE16_D] * scn + shn;
+                f32x4 w = pre[u % D16] * scn + shn;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[k] = ok ? fmaxf(w[k], floor_v) : 0.f;
                 store_px(real ? nxt : dump, real ? p : 0, w);
             }
         };
+        auto issue_first = [&]() {          // the first D16 items of a plane (issue() ignores items >= 8)
+            issue(std::integral_constant<int, 0>{});
+            issue(std::integral_constant<int, 1>{});
+            issue(std::integral_constant<int, (D16 > 2 ? 2 : 8)>{});
+            issue(std::integral_constant<int, (D16 > 3 ? 3 : 8)>{});
+            issue(std::integral_constant<int, (D16 > 4 ? 4 : 8)>{});
+            issue(std::integral_constant<int, (D16 > 5 ? 5 : 8)>{});
+        };
+        static_assert(D16 >= 2 && D16 <= 6, "staging items in flight");
         f32x4 aq[2][NTERM];                  // A fragments of the current and of the next 16-row tile
         f32x4 bx[NTERM][AN], by[NTERM][AN];  // B fragments of the current and of the next step
         auto load_b = [&](f32x4 (*bf)[AN], int wsel) {
@@ -449,11 +463,12 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 #pragma unroll
             for (int s = 0; s < NTERM; ++s) af[s] = lds4[lbase[i16] + osel + s];
         };
-        // (opaque to the optimizer: it would otherwise hoist lbase[i] + offset for all nine steps out of the loop - 54 registers)
+        // (the lane's unit is made opaque at every use: the optimizer would otherwise hoist the selects - and lbase[i] + offset for
+        //  all nine steps, 54 registers - out of the plane-pair loop; it even factors sel(a + s, b + s) into sel(a, b) + s to do so)
         auto sel = [&](int x0, int x1) {
-            int v = hik ? x1 : x0;
-            asm volatile("" : "+v"(v));
-            return v;
+            int hk = hik;
+            asm volatile("" : "+v"(hk));
+            return hk ? x1 : x0;
         };
 #define IC(n) std::integral_constant<int, n>{}
         // One scheduling region per half step: MT * AN * 3 matrix instructions, the A fragments one row tile ahead, in the first
@@ -477,14 +492,14 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     if constexpr (half == 0) load_b(bn, w_next);
 #ifndef M16_NO_STAGE
 #ifndef M16_NO_FINISH
-                    if constexpr (fin >= 0) finish(IC(fin));              // (reads pre[fin % PIPE16_D] before issue below refills it)
+                    if constexpr (fin >= 0) finish(IC(fin));              // (reads pre[fin % D16] before issue below refills it)
 #endif
 #endif
                 }
 #ifndef M16_NO_STAGE
                 if (ii == 1 % MT) {
 #ifndef M16_NO_ISSUE
-                    if constexpr (fin >= 0) issue(IC(fin + PIPE16_D));
+                    if constexpr (fin >= 0) issue(IC(fin + D16));
 #endif
                 }
 #endif
@@ -526,9 +541,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const int cn2 = cp + 2 < nchunks ? cp + 2 : cp + 1;      // after the last pair: a harmless re-fetch
             // ---- even plane (slot 0): taps (0,1) (2,3) (4,5) (6,7); plane cp + 1 is staged into slot 1
             phase(cp + 1, 1);
-            issue(IC(0));
-            issue(IC(1));
-            issue(IC(2));
+            issue_first();
             hstep(IC(0), IC(0), IC(1), bx, by, sel(bo(cp, 2), bo(cp, 3)), O0, O1);
             hstep(IC(1), IC(1), IC(1), bx, by, 0, O0, O1);
             hstep(IC(0), IC(2), IC(1), by, bx, sel(bo(cp, 4), bo(cp, 5)), O1, O2);
@@ -542,9 +555,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             // ---- (8 | 0 of the odd plane), then the odd plane (slot 1): (1,2) (3,4) (5,6) (7,8); plane cp + 2 goes to slot 0 once
             // every wave is past the straddling step
             phase(cp + 2, 0);
-            issue(IC(0));
-            issue(IC(1));
-            issue(IC(2));
+            issue_first();
             hstep(IC(0), IC(-1), IC(1), bx, by, sel(bo(cp + 1, 1), bo(cp + 1, 2)), O4, O5);
             hstep(IC(1), IC(-1), IC(1), bx, by, 0, O4, O5);
             __syncthreads();                 // slot 0 is free
