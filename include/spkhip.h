@@ -44,7 +44,7 @@ int spk_build_flags(void);
                                 output gradient this launch produces (dz = out * mask; mask = bn_act > 0, or
                                 bn_raw*scale+shift > 0 when bn_act is NULL; bn4 = [mean, invstd, scale, shift][Cout]) */
 
-/* kernel form (results are bit-identical to the plain kernel on the same tile); "experimental" = needs spk_build_flags() & 1 */
+/* kernel form (results are bit-identical to the plain kernel on the same tile, SPK_CONV_M16 excepted); "experimental" = needs spk_build_flags() & 1 */
 #define SPK_CONV_WS 128      /* experimental: producer / consumer form of spk_conv_mfma (split != 0, 9 taps, kc = 1; flags bits 8-9 = log2 of
                                 its consumer-wave channel groups) and of spk_conv_wgrad (split = 3, 3x3) */
 #define SPK_CONV_PIPE 1024   /* in-wave pipelined form: spk_conv_mfma (split = 3, 9 taps, kc = 1, <= 576 halo pixels, two halo
