@@ -52,10 +52,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 static bool bn_c_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
 
+#ifndef BN_STATS_BLOCKS
+#define BN_STATS_BLOCKS 4096
+#endif
 extern "C" int spk_bn_stats_blocks(long long N, int C) {
     (void)C;
     long long nb = (N + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    if (nb > BN_STATS_BLOCKS) nb = BN_STATS_BLOCKS;
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -217,7 +220,10 @@ extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 // tensor once, no grid-stride loop; > 0: that many persistent blocks at most) - each pair measured inside the training step
 // (profiles/r03_ab_runs.log).  tools/probe/stream_probe.hip: three 786 MB tensors stream at 5.8-6.05 TB/s from a covering grid and
 // at 4.5-5.0 TB/s from 2048 / 8192 persistent blocks - but a covering grid repeats the per-thread work (per-channel vectors, the
-// absmax commit) for every group, so it pays only with several groups per thread.
+// absmax commit) for every group, so it pays only with several groups per thread.  bn_apply: four groups, covering grid.
+// bn_bwd_apply (seven per-channel vectors, mask words, the f16 pair conversion): one group per thread from 2048 persistent blocks =
+// exactly the 8 blocks a CU holds, no block is ever launched behind another one (3.6 ms over its 30 launches; 8192 blocks 4.3,
+// 32768 blocks 5.7, covering grids 4.6-5.8).
 #ifndef BN_APPLY_U
 #define BN_APPLY_U 4
 #endif
@@ -228,7 +234,7 @@ extern "C" int spk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 #define BN_BWD_APPLY_U 1
 #endif
 #ifndef BN_BWD_APPLY_CAP
-#define BN_BWD_APPLY_CAP 8192
+#define BN_BWD_APPLY_CAP 2048
 #endif
 static int stream_grid(long long nquads, int per_thread = 1, int cap = 8192) {
     long long nb = (nquads + 256LL * per_thread - 1) / (256LL * per_thread);
@@ -503,14 +509,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef,
                                                            float* __restrict__ draw, float* __restrict__ dz_out,
-                                                           long long nquads, int C, int mode, unsigned* __restrict__ amax_out,
+                                                           unsigned nquads, int C, int mode, unsigned* __restrict__ amax_out,
                                                            const unsigned* __restrict__ pair_scale) {
     const int cmask = C - 1;
     float mx = 0.f;
     const float sig = pair_scale ? spk_sigma_from_amax_bits(*pair_scale) : 1.f;
     constexpr int U = BN_BWD_APPLY_U;
-    const long long stride = (long long)gridDim.x * 256;
-    const int lg = 31 - __builtin_clz((unsigned)C);          // C is a power of two
+    // 32-bit group indices (the host checks nquads < 2^31): the pixel of a group is a shift, its mask word one multiply-add
+    const unsigned stride = gridDim.x * 256u;
+    const int lgq = 29 - __builtin_clz((unsigned)C);         // log2(C / 4): 16-byte groups per pixel (C is a power of two)
+    const unsigned cw = (unsigned)C >> 5;
     // (C <= 1024: a thread stays on the channels of its first group - see bn_apply_kernel - the seven per-channel vectors once)
     const bool fixed_c = C <= 1024;
     const int c0 = (threadIdx.x * 4) & cmask;
@@ -520,25 +528,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         psc = *(const f32x4*)(scale + c0);
         psh = *(const f32x4*)(shift + c0);
     }
-    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < nquads; i0 += stride * U) {
+    for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < nquads; i0 += stride * U) {
         f32x4 rvv[U], dv[U], av[U];
         unsigned mw[U];
-        long long idx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {          // all loads of the U groups first (a group past the end re-reads group i0)
-            const long long i = i0 + stride * u;
-            idx[u] = i < nquads ? i : i0;
-            const long long off = idx[u] * 4;
+            const unsigned i = i0 + stride * u;
+            const unsigned ii = i < nquads && i >= i0 ? i : i0;
+            const size_t off = (size_t)ii * 4;
             rvv[u] = ld_stream(raw + off);
             dv[u] = ld_stream(dy + off);
-            if (mode == MASK_BITS) mw[u] = ((const unsigned*)act)[(off >> lg) * (C >> 5) + ((int)(off & cmask) >> 5)];
+            if (mode == MASK_BITS) mw[u] = ((const unsigned*)act)[(size_t)(ii >> lgq) * cw + (((ii * 4u) & (unsigned)cmask) >> 5)];
             else if (mode == MASK_ACT) av[u] = *(const f32x4*)(act + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + stride * u;
-            if (i >= nquads) continue;
-            const int c = fixed_c ? c0 : (int)((i * 4) & cmask);
+            const unsigned i = i0 + stride * u;
+            if (i >= nquads || i < i0) continue;
+            const int c = fixed_c ? c0 : (int)((i * 4u) & (unsigned)cmask);
             if (!fixed_c) {
                 pmu = *(const f32x4*)(mean + c);
                 pis = *(const f32x4*)(invstd + c);
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                     psh = *(const f32x4*)(shift + c);
                 }
             }
-            const long long off = i * 4;
+            const size_t off = (size_t)i * 4;
             const f32x4 rv = rvv[u];
             f32x4 d = dv[u];
             if (mode == MASK_BITS) {
@@ -588,8 +595,9 @@ extern "C" int spk_bn_bwd_apply(const float* dy, const float* raw, const float* 
     SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_apply: mask_mode=%d", mask_mode);
     SPK_REQUIRE((mask_mode != MASK_ACT && mask_mode != MASK_BITS) || act, "spk_bn_bwd_apply: MASK_ACT / MASK_BITS need the activated tensor / its sign bits");
     const long long nquads = N * C / 4;
+    SPK_REQUIRE(nquads < 2147483647LL / 8, "spk_bn_bwd_apply: %lld values exceed the 32-bit group index of the kernel", N * C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nquads, BN_BWD_APPLY_U, BN_BWD_APPLY_CAP)), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean,
-                       invstd, scale, shift, coef, draw, dz_out, nquads, C, mask_mode, amax_out, pair_scale);
+                       invstd, scale, shift, coef, draw, dz_out, (unsigned)nquads, C, mask_mode, amax_out, pair_scale);
     SPK_LAUNCH_CHECK("spk_bn_bwd_apply");
     return 0;
 }
