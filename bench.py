@@ -106,6 +106,11 @@ def parse():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the comparison run on the native fp32 matrix instruction (profiled "
                                                                 "runs: keeps its kernels out of the trace)")
     ap.add_argument("--no-f16-window", action="store_true", help="skip the operand-scale window counters (f16x3 mode)")
+    ap.add_argument("--lengths", type=int, default=8, help="distinct chunk lengths of --frames-range (one cached hipGraph each)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the bounded extra legs of the default N = 1 line (after the timed region, never part of `value`): "
+                         "`ingest` (loader-inclusive step), `extra.c5` (predict bs 512 with its own roofline object), `extra.c4` "
+                         "(ResNet-101, S 5994, three cached chunk lengths in [200, 400])")
     a = ap.parse_args()
     if a.config == "c1":
         a.batch, a.frames, a.speakers = 32, 200, 10
@@ -263,6 +268,100 @@ def embedding_parity(dev):
     return float((1.0 - cos).max())
 
 
+def roofline_object(recs, npass):
+    """The `roofline` object from an instrumented pass (ops.PROFILE records of `npass` steps, train or predict): the dominant
+    kernel by device time priced against BOTH ceilings - matrix FLOP/s of its operand mode and HBM bytes/s of its algorithmic
+    traffic (every tensor it must read or write, once) - the larger fraction names the binding one."""
+    # an event pair around NOTHING still measures the marker packets themselves (tens of microseconds on ROCm):
+    # calibrate that bracket overhead on the same stream and subtract it from every bracketed launch
+    empty = []
+    for _ in range(64):
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        a1.record()
+        empty.append((a0, a1))
+    torch.cuda.synchronize()
+    overhead_ms = sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
+    agg = {}
+    for name, flops, e0, e1, nbytes in recs:
+        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+        a[0] += max(e0.elapsed_time(e1) - overhead_ms, 1e-3) * 1e-3
+        a[1] += flops
+        a[2] += 1
+        a[3] += nbytes
+    name, (tsum, fsum, n, bsum) = max(agg.items(), key=lambda kv: kv[1][0])
+    ach = fsum / tsum / 1e12
+    ach_gbs = bsum / tsum / 1e9
+    # HBM traffic of that kernel: rocprofv3 cannot run inside this process, so this is the COMMITTED PMC pass of the
+    # same command (profiles/pmc_traffic.json) - used only while the device sources still hash to what it measured
+    traffic, traffic_note = None, "no committed PMC pass for this kernel"
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("spk_build", os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "build.py"))
+        bmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bmod)
+        pj = json.load(open(pmc))
+        ent = pj["kernels"].get(name.replace(",", ", "))
+        if pj.get("csrc_fingerprint") != bmod.csrc_fingerprint():
+            traffic_note = "committed PMC pass is stale (csrc changed since %s): refused" % pj.get("csrc_fingerprint")
+        elif ent:
+            traffic = round(ent["hbm_bytes_per_launch"])
+            traffic_note = ("committed PMC pass @ csrc %s: HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, separate "
+                            "rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json)" % pj["csrc_fingerprint"])
+    peak, peak_note = mfma_peak(name)
+    f_mfma, f_hbm = ach / peak, ach_gbs / PEAK_HBM_GBS
+    hbm_bound = f_hbm >= f_mfma
+    total_ms = sum(v[0] for v in agg.values()) / npass * 1e3
+    total_flops = sum(v[1] for v in agg.values()) / npass
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+            "achieved": round(ach_gbs if hbm_bound else ach, 2), "peak": PEAK_HBM_GBS if hbm_bound else round(peak, 1),
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(max(f_hbm, f_mfma), 4),
+            "mfma": {"achieved_tflops": round(ach, 2), "peak_tflops": round(peak, 1), "frac": round(f_mfma, 4),
+                     "peak_note": peak_note, "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)},
+            "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(f_hbm, 4),
+                    "algorithmic_bytes_per_launch": round(bsum / n),
+                    "note": "algorithmic bytes = inputs read once + outputs written once + every fused side stream "
+                            "(shortcut, BatchNorm-backward raw / side gradient, masks) + packed weights"},
+            "traffic": traffic, "traffic_note": traffic_note,
+            "launches_per_step": n // npass, "avg_launch_ms": round(tsum / n * 1e3, 4),
+            "event_bracket_overhead_us": round(overhead_ms * 1e3, 1),
+            "gflop_per_launch": round(fsum / n / 1e9, 3),
+            "step_level": {"kernel_ms_sum": round(total_ms, 3), "algorithmic_tflop": round(total_flops / 1e12, 3),
+                           "tflops": round(total_flops / 1e9 / max(total_ms, 1e-9), 1)},
+            "all_kernels": {k: {"ms_per_step": round(v[0] / npass * 1e3, 3),
+                                "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
+                                "algorithmic_gbs": round(v[3] / v[0] / 1e9, 1) if v[3] else None,
+                                "launches_per_step": v[2] // npass} for k, v in sorted(agg.items())}}
+
+
+def extra_leg(name, argv, timeout):
+    """A bounded extra leg of the default line: `python bench.py <argv>` as a child process (fresh state, the very command a
+    user would type), its JSON line parsed and trimmed.  Never part of `value`; a failure is reported in the object, not hidden."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout after %d s" % timeout, "command": "python bench.py " + " ".join(argv)}
+    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    try:
+        j = json.loads(line)
+    except ValueError:
+        return {"error": "rc %d: %s" % (r.returncode, (r.stderr or "")[-400:]), "command": "python bench.py " + " ".join(argv)}
+    rf = j.get("roofline")
+    if rf:
+        rf = {k: v for k, v in rf.items() if k != "all_kernels"}
+    out = {k: j.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "first_loss",
+                                 "final_loss", "graph_replay_repacks_weights", "kernel_launches_per_step")}
+    out["roofline"] = rf
+    out["command"] = "python bench.py " + " ".join(argv)
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    log("extra leg %s: %s %s in %.1f s" % (name, out.get("value"), out.get("unit"), out["wall_s"]))
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh children - one process per GPU,
     torch.distributed.run on 127.0.0.1 - before this process has touched the GPU (it never does), relay their output
@@ -328,7 +427,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # SPK_FORCE_REDUCER=1 (parallel.reducer_forced): the N > 1 machinery - RCCL communicator, stage-segmented graphs, the
+    # all-reduce on the communication stream between the replays - on ONE rank, for a box with a single GPU
+    forced = world == 1 and os.environ.get("SPK_FORCE_REDUCER", "0") == "1"
+    if forced:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        s_.close()
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -367,10 +475,13 @@ def main():
         import random
         rng = random.Random(4321)
         lo, hi = args.frames_range
-        lens = [rng.randint(lo, hi) for _ in range(8)]      # 8 distinct lengths, cycled: --warmup 8 touches each once
-        sched = [lens[i % 8] for i in range(args.warmup + args.steps)]
+        lens = [rng.randint(lo, hi) for _ in range(args.lengths)]      # --lengths distinct lengths, cycled
+        sched = [lens[i % len(lens)] for i in range(args.warmup + args.steps)]
         var_x = {t: torch.randn(args.batch, FEAT, t, device=dev, generator=gen) for t in sorted(set(sched))}
     step_no = [0]
+    # the BASELINE configs[1] label belongs to exactly that configuration (a batch-64 rehearsal carried it)
+    headline = (args.arch == "resnet34" and nspk == SPK and var_x is None and args.batch == B_PER_GPU and args.frames == FRAMES
+                and args.mode == "train")
     eng = model.engine()
     if os.environ.get("SPK_SIDE_STREAM", "1") == "0":
         eng.use_side_stream = False
@@ -393,10 +504,10 @@ def main():
         from pytorch_kaldi_resnet_amd.engine import GraphedTrainStep
         # a capture failure is a real fault (HIP error, shape bug): surface it instead of silently timing another path
         if var_x is None:
-            graphed = graphs[args.frames] = GraphedTrainStep(eng, args.batch, args.frames, segmented=world > 1)
+            graphed = graphs[args.frames] = GraphedTrainStep(eng, args.batch, args.frames, segmented=red.active)
         else:
             for t in sorted(var_x, reverse=True):           # longest first: it sizes the shared pool
-                graphs[t] = GraphedTrainStep(eng, args.batch, t, segmented=world > 1,
+                graphs[t] = GraphedTrainStep(eng, args.batch, t, segmented=red.active,
                                              pool=graphed.pool() if graphed is not None else None)
                 graphed = graphed or graphs[t]
                 log("captured the step for %d frames" % t)
@@ -411,12 +522,12 @@ def main():
     def train_step():
         xb = cur_x()
         if graphed is not None and PROFILE_OFF():
-            loss, _, _ = graphs[xb.shape[2]](xb, y, red.on_stage_done if world > 1 else None)
+            loss, _, _ = graphs[xb.shape[2]](xb, y, red.on_stage_done if red.active else None)
             red.finish()
             opt.step()
             return loss
         opt.zero_grad(set_to_none=True)
-        loss, _, _ = eng.loss_and_grad(xb, y, red.on_stage_done if world > 1 else None)
+        loss, _, _ = eng.loss_and_grad(xb, y, red.on_stage_done if red.active else None)
         red.finish()
         opt.step()
         return loss
@@ -473,7 +584,8 @@ def main():
     log("timed region done: %.3f s for %d steps (host enqueue %.1f ms/step)" % (dt, args.steps, t_host / args.steps * 1e3))
 
     ingest = None
-    if args.ingest and args.mode == "train" and var_x is None:
+    want_extra = rank == 0 and world == 1 and headline and not args.no_extra
+    if (args.ingest or want_extra) and args.mode == "train" and var_x is None:
         # Loader-inclusive step (reference scripts/train_resnet.py:307-313: loader -> pinned H2D -> step): every rank reads
         # its own seeded ark through libspkio (pread of the cropped frames on a thread pool into a pinned ring, guarded by
         # copy events), the copy runs on the loader's copy stream under the previous step's kernels, then the same replay.
@@ -500,10 +612,10 @@ def main():
         def ingest_step():
             xb, yb = next(it)
             if graphed is not None:
-                lossi, _, _ = graphed(xb, yb, red.on_stage_done if world > 1 else None)
+                lossi, _, _ = graphed(xb, yb, red.on_stage_done if red.active else None)
             else:
                 opt.zero_grad(set_to_none=True)
-                lossi, _, _ = eng.loss_and_grad(xb, yb, red.on_stage_done if world > 1 else None)
+                lossi, _, _ = eng.loss_and_grad(xb, yb, red.on_stage_done if red.active else None)
             red.finish()
             opt.step()
             return lossi
@@ -557,79 +669,24 @@ def main():
             raise SystemExit("bench: %d staged values saturate fp16 under their scale slot - an operand-scale bound is wrong" % sat)
 
     roofline = None
-    if rank == 0 and not args.no_roofline and args.mode == "train":
+    if rank == 0 and not args.no_roofline:
         # instrumented pass: same steps, every launch bracketed by HIP events on its launch stream; the side stream
         # for weight gradients is folded into the main stream here so kernels do not overlap while being timed
         eng.use_side_stream = False
         ops.PROFILE = []
-        for _ in range(2):
+        NPASS = 2
+        for _ in range(NPASS):
             # rank-local: no collective may be issued here, the other ranks are not in this pass
-            opt.zero_grad(set_to_none=True)
-            eng.loss_and_grad(x, y, None)
-            opt.step()
+            if args.mode == "train":
+                opt.zero_grad(set_to_none=True)
+                eng.loss_and_grad(x, y, None)
+                opt.step()
+            else:
+                model.predict(x)
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         eng.use_side_stream = True
-        # an event pair around NOTHING still measures the marker packets themselves (tens of microseconds on ROCm):
-        # calibrate that bracket overhead on the same stream and subtract it from every bracketed launch
-        empty = []
-        for _ in range(64):
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            a1.record()
-            empty.append((a0, a1))
-        torch.cuda.synchronize()
-        overhead_ms = sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
-        agg = {}
-        for name, flops, e0, e1, nbytes in recs:
-            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-            a[0] += max(e0.elapsed_time(e1) - overhead_ms, 1e-3) * 1e-3
-            a[1] += flops
-            a[2] += 1
-            a[3] += nbytes
-        name, (tsum, fsum, n, bsum) = max(agg.items(), key=lambda kv: kv[1][0])
-        ach = fsum / tsum / 1e12
-        ach_gbs = bsum / tsum / 1e9
-        # HBM traffic of that kernel: rocprofv3 cannot run inside this process, so this is the COMMITTED PMC pass of the
-        # same command (profiles/pmc_traffic.json) - used only while the device sources still hash to what it measured
-        traffic, traffic_note = None, "no committed PMC pass for this kernel"
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("spk_build", os.path.join(ROOT, "pytorch-kaldi-resnet_amd", "build.py"))
-            bmod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(bmod)
-            pj = json.load(open(pmc))
-            ent = pj["kernels"].get(name.replace(",", ", "))
-            if pj.get("csrc_fingerprint") != bmod.csrc_fingerprint():
-                traffic_note = "committed PMC pass is stale (csrc changed since %s): refused" % pj.get("csrc_fingerprint")
-            elif ent:
-                traffic = round(ent["hbm_bytes_per_launch"])
-                traffic_note = ("committed PMC pass @ csrc %s: HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                "rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json)" % pj["csrc_fingerprint"])
-        peak, peak_note = mfma_peak(name)
-        # The dominant kernel is priced against BOTH ceilings - matrix FLOP/s of its operand mode and HBM bytes/s of its
-        # algorithmic traffic (every tensor it must read or write, once) - and the larger fraction names the binding one.
-        f_mfma, f_hbm = ach / peak, ach_gbs / PEAK_HBM_GBS
-        hbm_bound = f_hbm >= f_mfma
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
-                    "achieved": round(ach_gbs if hbm_bound else ach, 2), "peak": PEAK_HBM_GBS if hbm_bound else round(peak, 1),
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(max(f_hbm, f_mfma), 4),
-                    "mfma": {"achieved_tflops": round(ach, 2), "peak_tflops": round(peak, 1), "frac": round(f_mfma, 4),
-                             "peak_note": peak_note, "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)},
-                    "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(f_hbm, 4),
-                            "algorithmic_bytes_per_launch": round(bsum / n),
-                            "note": "algorithmic bytes = inputs read once + outputs written once + every fused side stream "
-                                    "(shortcut, BatchNorm-backward raw / side gradient, masks) + packed weights"},
-                    "traffic": traffic, "traffic_note": traffic_note,
-                    "launches_per_step": n // 2, "avg_launch_ms": round(tsum / n * 1e3, 4),
-                    "event_bracket_overhead_us": round(overhead_ms * 1e3, 1),
-                    "gflop_per_launch": round(fsum / n / 1e9, 3),
-                    "all_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
-                                        "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
-                                        "algorithmic_gbs": round(v[3] / v[0] / 1e9, 1) if v[3] else None,
-                                        "launches_per_step": v[2] // 2} for k, v in sorted(agg.items())}}
-    headline = args.arch == "resnet34" and nspk == SPK and var_x is None
+        roofline = roofline_object(recs, NPASS)
     native = None
     if rank == 0 and world == 1 and args.mode == "train" and headline and graphed is not None and ops.SPLIT != 0 \
             and not args.no_roofline and not args.no_fp32_leg:
@@ -667,6 +724,20 @@ def main():
         eer = eer_leg(dev)
         log("EER leg done: hip %.4f vs cpu oracle %.4f (2048 utts, 20 k trials); subset hip %.4f vs cpu oracle %.4f" % (
             eer["hip_2048_utts"], eer["cpu_oracle_2048_utts"], eer["hip_subset"], eer["cpu_oracle_subset"]))
+    launch_desc = ("eager" if graphed is None else "hipGraph replay (%d graph%s%s)" % (
+        len(graphs) * len(graphed.segments), "s" if len(graphs) * len(graphed.segments) > 1 else "",
+        ", stage-segmented with the all-reduce between segments" if red.active else ""))
+    extra = None
+    if want_extra:
+        # release what this process holds on the device before the children allocate (graphs, pools, saved tensors)
+        graphed = None
+        graphs.clear()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        mf = ["--mfma", mfma_mode]
+        extra = {"c5": extra_leg("c5", ["--config", "c5", "--steps", "10", "--warmup", "3", "--no-extra"] + mf, 240),
+                 "c4": extra_leg("c4", ["--config", "c4", "--lengths", "3", "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
+                                        "--no-eer", "--no-f16-window", "--no-extra"] + mf, 300)}
     if rank == 0:
         gb = args.batch * world
         arch_name = {"resnet34": "ResNet-34", "resnet101": "ResNet-101"}[args.arch]
@@ -695,21 +766,22 @@ def main():
                        "global_batch": gb, "frames": args.frames if var_x is None else list(args.frames_range),
                        "feat_dim": FEAT, "speakers": nspk,
                        "parallelism": "dp%d" % world,
-                       "launch": ("eager" if graphed is None else "hipGraph replay (%d graph%s%s)" % (
-                           len(graphs) * len(graphed.segments), "s" if len(graphs) * len(graphed.segments) > 1 else "",
-                           ", stage-segmented with the all-reduce between segments" if world > 1 else "")),
+                       "launch": launch_desc,
+                       "collective": (None if not red.active else "%s all-reduce(%s) of the gradient arena per ResNet stage, "
+                                      "%d rank(s), %d calls" % (dist.get_backend(), red.op, world, red.calls)),
                        "mfma": mfma_mode},
             "first_loss": round(first_loss, 4), "final_loss": round(lossv, 4),
             "loss_decreased_on_the_fixed_batch": bool(lossv < first_loss) if args.mode == "train" else None,
             "graph_replay_repacks_weights": repack_ok, "eer": eer,
             "kernel_launches_per_step": (sum(v["launches_per_step"] for v in roofline["all_kernels"].values())
                                          if roofline else None),
-            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native, "ingest": ingest, "f16_window": f16_window,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_operand_mfma": native, "ingest": ingest, "extra": extra, "f16_window": f16_window,
             "embedding_cosine_delta_vs_oracle": parity,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()          # rank 0 is still in its instrumented pass while the others are done: leave together
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

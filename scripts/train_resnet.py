@@ -141,7 +141,10 @@ def main_worker(gpu, ngpus_per_node, args):
                                                                                 ngpus_per_node))
     optimizer = FlatSGD(model, args.lr, momentum=args.momentum, weight_decay=args.weight_decay, grad_scale=1.0 / world)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.epochs, eta_min=args.lr_final, last_epoch=-1)
-    reducer = GradAllReducer(model)
+    reducer = GradAllReducer(model)      # active with more than one rank (or SPK_FORCE_REDUCER=1 on a one-rank process group)
+    if reducer.active:
+        print("=> gradient all-reduce per ResNet stage on the communication stream: backend {}, {} rank(s), op {}".format(
+            dist.get_backend(), world, reducer.op))
     if args.resume:
         if os.path.isfile(args.resume):
             print("=> loading checkpoint '{}'".format(args.resume))
@@ -257,7 +260,7 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
     cache = getattr(eng, "_graph_cache", None)
     if cache is None and not args.no_graph:
         from pytorch_kaldi_resnet_amd.engine import GraphedStepCache
-        cache = eng._graph_cache = GraphedStepCache(eng, segmented=world > 1)
+        cache = eng._graph_cache = GraphedStepCache(eng, segmented=reducer.active)
     t_enq, n_enq = 0.0, 0
     end = time.time()
     t_epoch, n_utt = time.time(), 0
@@ -272,13 +275,13 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
             # all-reduce enqueued on the communication stream between them (overlaps the remaining backward)
             known = (audios.size(0), audios.size(2)) in cache.steps
             t_q = time.time()
-            loss, _, rank = cache(audios, target, reducer.on_stage_done if world > 1 else None)
+            loss, _, rank = cache(audios, target, reducer.on_stage_done if reducer.active else None)
             reducer.finish()
             if known:
                 t_enq, n_enq = t_enq + time.time() - t_q, n_enq + 1
         else:
             optimizer.zero_grad(set_to_none=True)
-            loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if world > 1 else None)
+            loss, _, rank = eng.loss_and_grad(audios, target, reducer.on_stage_done if reducer.active else None)
             reducer.finish()
         optimizer.step()
         n = audios.size(0)
@@ -292,6 +295,8 @@ def train(loader, model, optimizer, reducer, epoch, args, world):
             _progress("Epoch: [{}]".format(epoch), i, len(loader), [bt, dt_, losses, top1, top5])
     torch.cuda.synchronize()
     print(" * epoch {} train throughput {:.1f} utt/s (this rank)".format(epoch, n_utt / max(time.time() - t_epoch, 1e-9)))
+    if reducer.active:
+        print(" * epoch {} collectives issued so far: {}".format(epoch, reducer.calls))
     if cache is not None and n_enq:
         print(" * epoch {} captured steps: {} (chunk lengths {}), host enqueue {:.2f} ms/step over {} replays".format(
             epoch, len(cache), sorted({k[1] for k in cache.steps}), 1e3 * t_enq / n_enq, n_enq))

@@ -190,3 +190,148 @@ def test_variable_length_training_through_the_entry_point(tmp_path, reader):
     assert " * Acc@1 " in log.stdout and os.path.exists(os.path.join(d, "exp", "checkpoint_epoch2.pth.tar"))
     losses = [float(v) for v in re.findall(r"Loss ([0-9.e+-]+) \(", log.stdout)]
     assert all(np.isfinite(losses)) and len(losses) > 10
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _strip(sd):
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def test_reference_launch_path_on_rccl_with_one_rank(tmp_path):
+    """The launch path every stage of the reference's recipes uses (run_aam_v2.sh:86-102,114-126; scripts/train_resnet.py:
+    122-128,148-149; scripts/decode.py:55-57): --multiprocessing-distributed --world-size 1 --rank 0 --dist-url tcp://... ->
+    mp.spawn -> init_process_group('nccl') = RCCL, here with --gpu-num 1 (RCCL refuses two ranks on one device, so one rank
+    is what a one-GPU box can run).  Three runs of the same two epochs (tile autotuning pinned off, it is timing-based):
+      plain     --gpu 0: no process group, one captured graph per step
+      spawned   the reference's flags: RCCL communicator, DistributedSampler / rank-sharded reader, 'module.' checkpoint keys
+      forced    spawned + SPK_FORCE_REDUCER=1: the world > 1 machinery on that one rank - six stage-segmented hipGraph replays
+                sharing one memory pool with a real RCCL collective enqueued on the communication stream between them
+    All three must write bit-identical checkpoints (weights, BatchNorm buffers, momentum).  decode.py through the same launch
+    path must write the embeddings of the plain run."""
+    d = str(tmp_path)
+    n_spk = _make_data(d)
+    env = dict(os.environ, PYTHONPATH=ROOT, SPK_AUTOTUNE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = ["--workers", "0", "--batch-size", "16", "--print-freq", "1", "--arch", "resnet34", "--input-dim", "80",
+            "--loss-type", "AAM", "--pooling", "mean+std", "--epochs", "2", "--lr", "0.01", "--wd", "5e-4",
+            "--max-chunk-size", "200", "--train-list", os.path.join(d, "train.scp"), "--cv-list", os.path.join(d, "cv.scp"),
+            "--spk-num", str(n_spk), "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "7", "--native-reader"]
+
+    def dist_flags():
+        return ["--multiprocessing-distributed", "--world-size", "1", "--rank", "0", "--gpu-num", "1",
+                "--dist-url", "tcp://127.0.0.1:%d" % _free_port(), "--dist-backend", "nccl"]
+
+    def train(logdir, extra, env_extra=None):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_resnet.py")] + base + extra +
+                           ["--log-dir", os.path.join(d, logdir)], env=dict(env, **(env_extra or {})), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout
+
+    train("plain", ["--gpu", "0"])
+    out_s = train("spawned", dist_flags())
+    out_f = train("forced", dist_flags(), {"SPK_FORCE_REDUCER": "1"})
+    assert "gradient all-reduce per ResNet stage" not in out_s
+    assert "gradient all-reduce per ResNet stage on the communication stream: backend nccl, 1 rank(s)" in out_f
+    import re
+    calls = [int(v) for v in re.findall(r"collectives issued so far: (\d+)", out_f)]
+    steps = len(re.findall(r"Epoch: \[\d+\]\[", out_f))
+    assert calls and calls[-1] == 6 * steps, (calls, steps)            # head, layer4..1, stem per step
+    ck = {n: torch.load(os.path.join(d, n, "checkpoint_epoch1.pth.tar"), map_location="cpu", weights_only=True)
+          for n in ("plain", "spawned", "forced")}
+    assert all(k.startswith("module.") for k in ck["spawned"]["state_dict"])          # DDP-wrapped naming (train_resnet.py:283-289)
+    assert not any(k.startswith("module.") for k in ck["plain"]["state_dict"])
+    ref_sd = ck["plain"]["state_dict"]
+    for n in ("spawned", "forced"):
+        sd = _strip(ck[n]["state_dict"])
+        assert sorted(sd) == sorted(ref_sd)
+        for k, v in ref_sd.items():
+            assert torch.equal(v, sd[k]), (n, k)
+        for i, ent in ck["plain"]["optimizer"]["state"].items():
+            assert torch.equal(ent["momentum_buffer"], ck[n]["optimizer"]["state"][i]["momentum_buffer"]), (n, i)
+        assert float(ck[n]["best_acc1"]) == float(ck["plain"]["best_acc1"])
+    # extraction through the same launch path: rank file '0' instead of 'alone', same vectors
+    dec = ["--workers", "0", "--batch-size", "1", "--chunk-size", "-1", "--spk_num", str(n_spk), "--arch", "resnet34",
+           "--input-dim", "80", "--pooling", "mean+std", "--decode-scp", os.path.join(d, "decode.scp")]
+    for name, extra, model in (("emb_plain", ["--gpu", "0"], os.path.join(d, "plain", "checkpoint_epoch1.pth.tar")),
+                               ("emb_spawned", dist_flags()[:-2] + ["--dist-backend", "nccl"],
+                                os.path.join(d, "spawned", "checkpoint_epoch1.pth.tar"))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "decode.py")] + dec + extra +
+                           ["--model-path", model, "--out-path", os.path.join(d, name)], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a = open(os.path.join(d, "emb_plain", "alone")).read().splitlines()
+    b = open(os.path.join(d, "emb_spawned", "0")).read().splitlines()
+    assert sorted(a) == sorted(b) and len(a) == sum(1 for _ in open(os.path.join(d, "decode.scp")))
+
+
+def test_run_aam_cpu_sh_end_to_end(tmp_path):
+    """BASELINE configs[0] at its stated size through the shell entry point itself (reference run_aam_cpu.sh:60-110: 1 000
+    utterances of 200..260 frames x 80 mel, 10 speakers, batch 32, ResNet-34 + AAM, train -> decode -> mean -> cosine -> EER).
+    The recipe must run to the end, leave the checkpoints, one embedding per utterance, a score per trial and an EER file
+    whose number equals the EER recomputed here from the embeddings it wrote; the synthetic speakers (0.5 sigma mean offsets)
+    separate, so the EER must be far from chance."""
+    d = str(tmp_path / "exp")
+    r = subprocess.run(["bash", os.path.join(ROOT, "run_aam_cpu.sh"), d], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for f in ("checkpoint_epoch0.pth.tar", "checkpoint_epoch1.pth.tar", "train.log", "mean.vec", "scores", "eer_cosine"):
+        assert os.path.exists(os.path.join(d, f)), f
+    log = open(os.path.join(d, "train.log")).read()
+    assert "Epoch: [1][" in log and " * Acc@1 " in log and "train_loader samples: 30" in log          # 950 utterances / 32
+    import pytorch_kaldi_resnet_amd  # noqa: F401
+    from pytorch_kaldi_resnet_amd import scoring
+    emb = scoring.read_embeddings(os.path.join(d, "embeddings", "alone"))
+    assert len(emb) == 1000 and all(len(v) == 256 for v in emb.values())
+    n_trials = sum(1 for _ in open(os.path.join(d, "data", "trials")))
+    assert sum(1 for _ in open(os.path.join(d, "scores"))) == n_trials
+    txt = open(os.path.join(d, "eer_cosine")).read().strip()
+    assert txt.startswith("EER: ") and txt.endswith("%"), txt
+    eer_file = float(txt[len("EER: "):-1]) / 100
+    mean = scoring.compute_mean(os.path.join(d, "embeddings", "alone"))
+    sc, lab = scoring.cosine_score(emb, emb, os.path.join(d, "data", "trials"), mean)
+    eer_here = scoring.compute_eer(sc, lab)
+    print("run_aam_cpu.sh: EER %.4f (recomputed %.4f) over %d trials" % (eer_file, eer_here, n_trials))
+    assert abs(eer_file - eer_here) <= 1e-4 + 1e-9
+    assert eer_file < 0.35
+
+
+def test_resnet101_variable_length_through_the_entry_point(tmp_path):
+    """BASELINE configs[3] is ResNet-101 WITH variable-length batches: Bottleneck blocks (reference scripts/model.py:100-135,
+    resnet101 :314-321) through scripts/train_resnet.py --arch resnet101 --var-chunk, two chunk lengths, a few steps per epoch
+    (--max-steps).  One captured step per length out of the shared pool; finite, decreasing-on-average loss; a 1x1/3x3/1x1
+    checkpoint with the reference's key naming."""
+    import re
+    d = str(tmp_path)
+    n_spk = _make_data(d, per_spk=14, frames=240)
+    env = dict(os.environ, PYTHONPATH=ROOT, SPK_AUTOTUNE="0")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_resnet.py"), "--gpu", "0", "--workers", "2",
+           "--batch-size", "8", "--print-freq", "1", "--arch", "resnet101", "--input-dim", "80", "--loss-type", "AAM",
+           "--pooling", "mean+std", "--epochs", "2", "--lr", "0.01", "--lr-final", "0.001", "--wd", "5e-4", "--max-steps", "6",
+           "--var-chunk", "--min-chunk-size", "200", "--max-chunk-size", "216", "--chunk-quantum", "16",
+           "--train-list", os.path.join(d, "train.scp"), "--cv-list", os.path.join(d, "cv.scp"), "--spk-num", str(n_spk),
+           "--utt2spkid", os.path.join(d, "utt2spkid"), "--seed", "11", "--native-reader", "--log-dir", os.path.join(d, "exp")]
+    log = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert log.returncode == 0, log.stdout[-3000:] + log.stderr[-3000:]
+    assert "=> creating model 'resnet101'" in log.stdout
+    rep = re.findall(r"epoch (\d+) captured steps: (\d+) \(chunk lengths \[([0-9, ]+)\]\)", log.stdout)
+    assert rep, log.stdout[-2000:]
+    lengths = sorted(int(v) for v in rep[-1][2].split(","))
+    assert lengths == [200, 216], lengths
+    losses = [float(v) for v in re.findall(r"Epoch: \[\d+\].*Loss ([0-9.e+-]+) \(", log.stdout)]
+    assert len(losses) == 12 and all(np.isfinite(losses))
+    ck = torch.load(os.path.join(d, "exp", "checkpoint_epoch1.pth.tar"), map_location="cpu", weights_only=True)
+    import json
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys_resnet101_AAM.json")))     # recorded from the reference
+    assert sorted(ck["state_dict"]) == sorted(k for k, _ in keys)
+    for k, shape in keys:
+        if k != "last.weight":                                                                        # (fixture: another speaker count)
+            assert list(ck["state_dict"][k].shape) == shape, k
+    assert ck["arch"] == "resnet101"

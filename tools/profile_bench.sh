@@ -7,7 +7,7 @@ R=$(readlink -f "$(dirname "$0")/..")
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-eer --no-fp32-leg --no-f16-window $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-eer --no-fp32-leg --no-f16-window --no-extra $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- python3 "$R/bench.py" $ARGS > "$OUT/bench_line_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 "$R/bench.py" $ARGS --no-roofline > "$OUT/bench_line_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 "$R/bench.py" $ARGS --no-roofline > "$OUT/bench_line_write.json" 2> "$OUT/write.err"
