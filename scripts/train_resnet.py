@@ -119,6 +119,10 @@ def main_worker(gpu, ngpus_per_node, args):
                                 rank=args.rank)
     if args.seed is not None:
         np.random.seed(args.seed + max(args.rank, 0))
+        # the reference seeds torch in main() only (train_resnet.py:96-104), so its spawned workers initialise from an unseeded
+        # generator and rely on DDP's broadcast from rank 0; seeding here too makes a --multiprocessing-distributed run
+        # reproduce the --gpu run with the same --seed
+        torch.manual_seed(args.seed)
     torch.cuda.set_device(args.gpu)
     print("=> creating model '{}'".format(args.arch))
     model = NeuralSpeakerModel(spk_num=args.spk_num, feat_dim=args.input_dim, pooling=args.pooling, loss=args.loss_type,
