@@ -181,11 +181,16 @@ int spk_bn_apply(const float* raw, const float* scale, const float* shift, const
  * sign bits of the activated tensor ([pixel][C/32] words, spk_bn_apply mask_out) instead of the tensor */
 int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                       const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
-                      void* stream);
+                      unsigned* chan_amax /* optional [C], zeroed by the caller: atomicMax of the float bits of |dz| per CHANNEL
+                      (non-finite values left out) - the per-channel A of spk_bn_bwd_finalize */, void* stream);
 int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma, const float* invstd,
                         float* dgamma, float* dbeta, float* coef /*[3][C]*/, int accumulate, double* ws,
                         const unsigned* amax_in, const unsigned* raw_amax, const float* mean, unsigned* est_out /* optional
                         (needs the three before it): the spk_bnbwd_estimate bound, per channel, by atomicMax - saves that launch */,
+                        const unsigned* chan_amax /* optional [C] (spk_bn_bwd_reduce): the bound pairs every channel's own absmax
+                        of dz with its own k1 instead of the tensor-wide *amax_in (which may then be NULL).  Needed where the
+                        incoming gradient's range is unbounded per channel: the pooling layer's sqrt'(mean) at a tiny mean
+                        (scripts/model.py:453) is huge exactly in channels whose BatchNorm gamma is tiny */,
                         void* stream);
 int spk_bn_bwd_apply(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* coef, float* draw, float* dz_out, long long N,

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ act, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ partial,
-                                                            long long N, int C, int rows_per_block, int mode) {
+                                                            long long N, int C, int rows_per_block, int mode,
+                                                            unsigned* __restrict__ chan_amax) {
     __shared__ float red[256][8];
     const int tid = threadIdx.x;
     const int qpr = C >> 2;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (r1 > N) r1 = N;
     const f32x4 mu = *(const f32x4*)(mean + quad * 4), is = *(const f32x4*)(invstd + quad * 4);
     const f32x4 sc = *(const f32x4*)(scale + quad * 4), sh = *(const f32x4*)(shift + quad * 4);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f}, mx = {0.f, 0.f, 0.f, 0.f};
     for (long long r = r0 + prow; r < r1; r += rstep) {
         const long long off = r * C + quad * 4;
         const f32x4 rv = ld_stream(raw + off);
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const f32x4 xh = (rv - mu) * is;
         s += d;
         ss += d * xh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], spk_finite_abs(d[k]));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -417,11 +420,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             dst[k * 2 + 1] = a[4 + k];
         }
     }
+    if (chan_amax) {
+        // per-CHANNEL absmax of dz (float bits, atomicMax): the BatchNorm-backward bound then pairs every channel's own |dz| with
+        // its own k1 (bn_bwd_finalize chan_amax).  One tensor-wide absmax couples the channels: a gradient that is huge in a channel
+        // whose gamma is tiny (the pooling layer's sqrt'(mean) at a tiny mean, scripts/model.py:453) is multiplied by the LARGEST
+        // |k1| of the layer and the bound overshoots the values by that ratio - everything then sits low in its fp16 window.
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[tid][k] = mx[k];
+        __syncthreads();
+        if (tid < qpr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float m = 0.f;
+                for (int p = 0; p < rstep; ++p) m = fmaxf(m, red[p * qpr + tid][k]);
+                const unsigned bits = __float_as_uint(m);
+                unsigned* slot = chan_amax + tid * 4 + k;
+                if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+            }
+        }
+    }
 }
 
 extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float* act, const float* mean, const float* invstd,
                                  const float* scale, const float* shift, float* partial, long long N, int C, int mask_mode,
-                                 void* stream) {
+                                 unsigned* chan_amax, void* stream) {
     SPK_REQUIRE(dy && raw && mean && invstd && scale && shift && partial, "spk_bn_bwd_reduce: null pointer");
     SPK_REQUIRE(N > 0 && bn_c_ok(C), "spk_bn_bwd_reduce: N=%lld C=%d", N, C);
     SPK_REQUIRE(mask_mode >= 0 && mask_mode <= 3, "spk_bn_bwd_reduce: mask_mode=%d", mask_mode);
@@ -429,7 +452,7 @@ extern "C" int spk_bn_bwd_reduce(const float* dy, const float* raw, const float*
     const int nb = spk_bn_stats_blocks(N, C);
     const int rpb = (int)((N + nb - 1) / nb);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, raw, act, mean, invstd, scale,
-                       shift, partial, N, C, rpb, mask_mode);
+                       shift, partial, N, C, rpb, mask_mode, chan_amax);
     SPK_LAUNCH_CHECK("spk_bn_bwd_reduce");
     return 0;
 }
@@ -449,7 +472,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef, int accumulate,
                                                               const unsigned* __restrict__ amax_in, const unsigned* __restrict__ raw_amax,
-                                                              const float* __restrict__ mean, unsigned* __restrict__ est_out) {
+                                                              const float* __restrict__ mean, unsigned* __restrict__ est_out,
+                                                              const unsigned* __restrict__ chan_amax) {
     __shared__ double red[8][32][2];
     const int tid = threadIdx.x, c = tid & 31, row = tid >> 5;
     const int ch = blockIdx.x * 32 + c;
@@ -474,7 +498,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
         // |dz| <= A = absmax of the incoming gradient, |xhat| = |raw - mean| invstd <= (R + |mean|) invstd with R = absmax(raw),
         // both slots complete before this launch; bnbwd_bound() adds the rounding slack of the fp32 evaluation.
         if (est_out) {
-            const float e = bnbwd_bound(k1, m1, m2, mean[ch], invstd[ch], __uint_as_float(*amax_in), __uint_as_float(*raw_amax));
+            // chan_amax (when the reduction pass produced it): A is this channel's own absmax of dz instead of the tensor's
+            const float A = chan_amax ? __uint_as_float(chan_amax[ch]) : __uint_as_float(*amax_in);
+            const float e = bnbwd_bound(k1, m1, m2, mean[ch], invstd[ch], A, __uint_as_float(*raw_amax));
             const unsigned bits = __float_as_uint(e);
             if (bits > __hip_atomic_load(est_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(est_out, bits);
         }
@@ -484,20 +510,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const T* __restric
 extern "C" int spk_bn_bwd_finalize(const float* partial, int nblk, int C, double count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate,
                                    double* ws, const unsigned* amax_in, const unsigned* raw_amax, const float* mean,
-                                   unsigned* est_out, void* stream) {
+                                   unsigned* est_out, const unsigned* chan_amax, void* stream) {
     SPK_REQUIRE(partial && gamma && invstd && dgamma && dbeta && coef, "spk_bn_bwd_finalize: null pointer");
     SPK_REQUIRE(nblk > 0 && C > 0 && count > 0, "spk_bn_bwd_finalize: bad sizes");
-    SPK_REQUIRE(!est_out || (amax_in && raw_amax && mean), "spk_bn_bwd_finalize: est_out needs amax_in, raw_amax and mean");
+    SPK_REQUIRE(!est_out || ((amax_in || chan_amax) && raw_amax && mean),
+                "spk_bn_bwd_finalize: est_out needs amax_in (or chan_amax), raw_amax and mean");
     hipStream_t st = (hipStream_t)stream;
     if (spk_bn_finalize_workspace(nblk, C)) {
         SPK_REQUIRE(ws, "spk_bn_bwd_finalize: %d partial rows need the fp64 workspace", nblk);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(spk_ceil_div(C, 32), BN_STAGE_ROWS), dim3(256), 0, st, partial, ws, nblk, C);
         SPK_LAUNCH_CHECK("spk_bn_bwd_finalize(fold)");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, ws, BN_STAGE_ROWS, C, count,
-                           gamma, invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out);
+                           gamma, invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out, chan_amax);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(spk_ceil_div(C, 32)), dim3(256), 0, st, partial, nblk, C, count, gamma,
-                           invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out);
+                           invstd, dgamma, dbeta, coef, accumulate, amax_in, raw_amax, mean, est_out, chan_amax);
     }
     SPK_LAUNCH_CHECK("spk_bn_bwd_finalize");
     return 0;

@@ -149,6 +149,13 @@ class Engine:
         self.pair_draw = os.environ.get("SPK_PAIR_DRAW", "1") == "1"
         # diagnostics (tests / bench, never the timed path): when a [4] int64 device tensor, every tensor that an f16x3
         # matrix-core kernel stages is also run through spk_f16_window_count under the scale slot its consumer uses
+        # The blocks of the LAST stage sit between the pooling layer and the first BatchNorm backward + convolution that bound the
+        # gradient's range again: sqrt'(mean) of scripts/model.py:453 is unbounded (1e8 x the rest for a row mean of 1e-20) and
+        # travels down the identity shortcuts as dout.  There the BatchNorm-backward scale bound pairs every channel's own absmax
+        # of dz with its own gamma*invstd (spk_bn_bwd_reduce chan_amax) - a tensor-wide absmax times the layer's largest |k1|
+        # overshoots the values by the ratio of the two and pushes the whole pair tensor out of its fp16 window.  Costs the
+        # stand-alone reduction pass for two more 100 MB tensors per step (their statistics no longer come from an epilogue).
+        self.chan_amax = os.environ.get("SPK_CHAN_AMAX", "1") == "1"
         self.window_counts = None
         self.bound_log = None          # diagnostics: when a list, (Cout, k, bound slot, true-absmax slot) of every BatchNorm-backward scale
 
@@ -445,6 +452,7 @@ class Engine:
             for li in range(1, 5):
                 stage_of += [li] * len(getattr(m.res, "layer%d" % li))
             part = None      # BatchNorm-backward partial sums of `d`, when the producing dgrad epilogue made them
+            last_stage = stage_of[-1]
             for bi in range(nblk - 1, -1, -1):
                 # the gradient this block hands down is the gradient wrt the previous block's (or the stem's)
                 # BN+ReLU output: let the data-gradient epilogue reduce that BatchNorm's backward statistics
@@ -452,7 +460,10 @@ class Engine:
                     prev = (saved["blocks"][bi - 1]["raws"][-1], self.blocks[bi - 1].bns[-1].t4)
                 else:
                     prev = (saved["raw0"], self.stem_bn.t4)
-                d, part, d_amax = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc, part, prev, d_amax, amx)
+                chan = self.chan_amax and amx is not None and stage_of[bi] == last_stage
+                if chan and bi > 0 and stage_of[bi - 1] == last_stage:
+                    prev = None            # that BatchNorm's statistics come from its own reduction pass, with per-channel absmax
+                d, part, d_amax = self._block_bwd(self.blocks[bi], saved["blocks"][bi], d, acc, part, prev, d_amax, amx, chan)
                 saved["blocks"][bi] = None
                 if on_stage_done and (bi == 0 or stage_of[bi - 1] != stage_of[bi]):
                     self._join_wgrad()
@@ -466,7 +477,7 @@ class Engine:
             if on_stage_done:
                 on_stage_done("stem")
 
-    def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None, dout_amax=None, amx=None):
+    def _block_bwd(self, b, rec, dout, acc, dout_partial=None, prev=None, dout_amax=None, amx=None, chan=False):
         """Backward of one residual block.  -> (gradient wrt the block input, BN-backward partial sums of it or None,
         absmax slot of it or None).
 
@@ -475,7 +486,8 @@ class Engine:
         stride-1 conv_i the BatchNorm backward of bn_i is applied inside the data-gradient kernel's input staging
         (IN_BNBWD): no separate apply pass; the kernel writes draw_i (for the weight gradient) and, for the last BN,
         dz (the shortcut gradient) as side products.  Stride-2 convs (parity-class launches) keep the separate pass.
-        amx (f16x3 backward): the step's absmax slot table; g / draw / dx each carry a slot (see Engine.backward)."""
+        amx (f16x3 backward): the step's absmax slot table; g / draw / dx each carry a slot (see Engine.backward).
+        chan: the last BatchNorm's scale bound uses the per-channel absmax of dz (Engine.chan_amax; dout_partial must be None)."""
         x, raws, out = rec["x"], rec["raws"], rec["out"]
         n = len(b.convs)
         g, g_part, g_amax, dz = dout, dout_partial, dout_amax, None
@@ -506,11 +518,13 @@ class Engine:
             raw_amax = rec["raw_amax"][i] if f16 else None
             if self.fuse_bn_apply and c.stride == 1 and (self.fuse_apply_min_c <= c.cout <= self.fuse_apply_max_c
                                                          or (c.k == 1 and self.fuse_apply_1x1)):
+                ca = None
                 if g_part is None:
-                    g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW)
+                    ca = amx.take_n(c.cout) if (chan and last and f16) else None
+                    g_part = ops.bn_bwd_partial(g, raw, act, bn.t4, MASK_ACT if last else MASK_RAW, chan_amax=ca)
                 est = take() if f16 else None
                 coef = ops.bn_bwd_coef(g_part, raw.numel() // raw.shape[-1], bn.h.weight.data, bn.t4, bn.h.weight.grad,
-                                       bn.h.bias.grad, acc, amax_in=g_amax, raw_amax=raw_amax, est_out=est)
+                                       bn.h.bias.grad, acc, amax_in=g_amax, raw_amax=raw_amax, est_out=est, chan_amax=ca)
                 draw = torch.empty_like(raw)
                 # the shortcut gradient dz = dout*[out > 0]: with an identity shortcut and sign masks it is never stored - the
                 # first conv's data-gradient epilogue re-forms it from dout and the mask bits
@@ -543,10 +557,11 @@ class Engine:
                     # data-gradient epilogue re-forms it from dout and the bits (as in the fused form above)
                     bits = rec.get("mask")
                     lazy_dz = b.ds is None and bits is not None and n > 1
+                    ca = amx.take_n(c.cout) if (chan and pairs and g_part is None) else None
                     draw = ops.bn_backward(g, raw, bits if bits is not None else out, bn.t4, bn.h.weight.data, bn.h.weight.grad,
                                            bn.h.bias.grad, MASK_BITS if bits is not None else MASK_ACT,
                                            dz_out=None if lazy_dz else g, accumulate=acc, partial=g_part, amax_out=draw_amax,
-                                           pair=pair)
+                                           pair=pair, chan_amax=ca)
                     dz = None if lazy_dz else g                         # (dout now holds dz)
                 else:
                     draw = ops.bn_backward(g, raw, None, bn.t4, bn.h.weight.data, bn.h.weight.grad, bn.h.bias.grad, MASK_RAW,

@@ -41,8 +41,8 @@ _SIGS = {
     "spk_bn_finalize": [_P, _I, _I, _D] + [_P] * 9 + [_F, _F, _P, _P, _P, _P],
     "spk_bn_eval_coeffs": [_P] * 6 + [_I, _F, _P],
     "spk_bn_apply": [_P] * 8 + [_L, _I, _I, _P, _P],
-    "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P],
-    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P, _P, _P, _P, _P],
+    "spk_bn_bwd_reduce": [_P] * 8 + [_L, _I, _I, _P, _P],
+    "spk_bn_bwd_finalize": [_P, _I, _I, _D] + [_P] * 5 + [_I, _P, _P, _P, _P, _P, _P, _P],
     "spk_bn_bwd_apply": [_P] * 10 + [_L, _I, _I, _P, _P, _P],
     "spk_absmax": [_P, _P, _L, _P],
     "spk_bnbwd_estimate": [_P, _P, _P, _I, _P, _P, _P, _P],

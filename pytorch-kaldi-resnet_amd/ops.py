@@ -40,9 +40,16 @@ class AmaxPool:
     kernel) per gradient tensor of a step, taken in a fixed order so that a captured hipGraph sees the same addresses on
     every replay; zeroed once at the start of the step."""
 
-    def __init__(self, device, n=1024):
+    def __init__(self, device, n=4096):
         self.table = torch.zeros(n, device=device, dtype=torch.int32)
         self.next = 0
+
+    def take_n(self, n):
+        """n consecutive slots (a per-channel absmax row, spk_bn_bwd_reduce chan_amax)"""
+        i = self.next
+        assert i + n <= self.table.numel(), "AmaxPool exhausted"
+        self.next = i + n
+        return self.table[i:i + n]
 
     def reset(self):
         self.table.zero_()
@@ -576,13 +583,14 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label="conv_wgrad_wm_kernel" if wm
+         label=("conv_wgrad_wm_kernel" if wm
          else ("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
          else ("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
          else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp
          else ("conv_wgrad_split_kernel<%d,%d,%d,%d,%d>" % (
              ksize * ksize, 4 // WN, WN, split, 4 if ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize) <= 128 else 5)) if split
-         else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN),
+         else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN)) + (
+             " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize, nbytes=4.0 * (x.numel() + dy.numel() + nbytes / 4))
     call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw
@@ -659,13 +667,15 @@ def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, 
 
 
 def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,
-                partial=None, amax_out=None, pair=None):
+                partial=None, amax_out=None, pair=None, chan_amax=None):
     """Full BN backward (reduce -> finalize -> apply). bn4 = [mean, invstd, scale, shift] rows.
     `partial`: (sum dz, sum dz*xhat) rows already produced by the data-gradient epilogue (EPI_BNBWD) - skips the
     reduction pass.  Returns draw (gradient wrt the raw conv output).
     pair = (amax_in, raw_amax, est) (f16x3 mode): draw is written as an f16 PAIR tensor (include/spkhip.h) scaled by the sigma
     of `est`, the slot the finalize fills with the rigorous bound of |draw| from amax_in (absmax of dy) and raw_amax (absmax of
-    raw): the data gradient and the weight gradient that consume draw stage it by plain copy with that slot as their scale."""
+    raw): the data gradient and the weight gradient that consume draw stage it by plain copy with that slot as their scale.
+    chan_amax ([C] int32 zeros, with pair): the reduction pass also takes the absmax of dz per CHANNEL and the bound uses it
+    instead of the tensor-wide amax_in (needs partial=None: the reduction runs here)."""
     C = raw.shape[-1]
     N = raw.numel() // C
     coef = torch.empty(3, C, device=raw.device, dtype=torch.float32)
@@ -673,12 +683,13 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
         nblk = hip.lib().spk_bn_stats_blocks(N, C)
         part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
         call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
-             N, C, mask_mode, stream())
+             N, C, mask_mode, ptr(chan_amax), stream())
     else:
+        assert chan_amax is None, "chan_amax comes out of the reduction pass: partial must be None"
         part, nblk = partial, partial.shape[0]
     call("spk_bn_bwd_finalize", ptr(part), nblk, C, float(N), ptr(gamma), ptr(bn4[1]), ptr(dgamma), ptr(dbeta), ptr(coef),
          1 if accumulate else 0, ptr(_ws64(raw.device)), ptr(pair[0]) if pair else None, ptr(pair[1]) if pair else None,
-         ptr(bn4[0]) if pair else None, ptr(pair[2]) if pair else None, stream())
+         ptr(bn4[0]) if pair else None, ptr(pair[2]) if pair else None, ptr(chan_amax) if pair else None, stream())
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
@@ -686,7 +697,8 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     return draw_out
 
 
-def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, amax_in=None, raw_amax=None, est_out=None):
+def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, amax_in=None, raw_amax=None, est_out=None,
+                chan_amax=None):
     """BatchNorm-backward finalize only: dgamma, dbeta and the coefficient rows [gamma*invstd, mean(dz), mean(dz*xhat)].
     amax_in + raw_amax + est_out (f16x3 mode): also the RIGOROUS upper bound of the values the fused BatchNorm-backward data
     gradient will stage (spk_bnbwd_estimate), from the absmax of the incoming gradient and of the raw tensor."""
@@ -695,18 +707,20 @@ def bn_bwd_coef(partial, count, gamma, bn4, dgamma, dbeta, accumulate=False, ama
     assert est_out is None or (amax_in is not None and raw_amax is not None)
     call("spk_bn_bwd_finalize", ptr(partial), partial.shape[0], C, float(count), ptr(gamma), ptr(bn4[1]), ptr(dgamma),
          ptr(dbeta), ptr(coef), 1 if accumulate else 0, ptr(_ws64(gamma.device)), ptr(amax_in) if est_out is not None else None,
-         ptr(raw_amax) if est_out is not None else None, ptr(bn4[0]) if est_out is not None else None, ptr(est_out), stream())
+         ptr(raw_amax) if est_out is not None else None, ptr(bn4[0]) if est_out is not None else None, ptr(est_out),
+         ptr(chan_amax) if est_out is not None else None, stream())
     return coef
 
 
-def bn_bwd_partial(dy, raw, act, bn4, mask_mode):
-    """Stand-alone reduction (sum dz, sum dz*xhat) when no data-gradient epilogue produced it."""
+def bn_bwd_partial(dy, raw, act, bn4, mask_mode, chan_amax=None):
+    """Stand-alone reduction (sum dz, sum dz*xhat) when no data-gradient epilogue produced it.  chan_amax ([C] int32 zeros):
+    also the absmax of dz per channel (float bits)."""
     C = raw.shape[-1]
     N = raw.numel() // C
     nblk = hip.lib().spk_bn_stats_blocks(N, C)
     part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
     call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
-         N, C, mask_mode, stream())
+         N, C, mask_mode, ptr(chan_amax), stream())
     return part
 
 

@@ -39,6 +39,8 @@ for step in "$@"; do
         smoke)         run smoke 200 python3 __graft_entry__.py smoke ;;
         profile)       run profile 600 bash tools/profile_bench.sh $D/prof ;;
         profile_sq)    run profile_sq 400 bash tools/profile_sq.sh $D/sq ;;
+        profile_sq2)   run profile_sq2 500 bash tools/profile_sq2.sh $D/sq2 ;;
+        bench_shapes)  SPK_LABEL_SHAPES=1 run bench_shapes 300 python3 bench.py --steps 10 --warmup 3 $FAST --no-extra ;;
         trace_forced)  mkdir -p $D/trace_forced
                        echo "=== trace_forced $(date +%T)" | tee -a $D/progress.log
                        ( cd /tmp && SPK_FORCE_REDUCER=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/$D/trace_forced --output-format csv -- \
