@@ -24,6 +24,13 @@ void spk_ark_close_all(void);
 int64_t spk_text_vectors_bound(int n, int D, const char* const* keys);
 int64_t spk_format_text_vectors(int n, int D, const float* v, const char* const* keys, char* out, int64_t cap,
                                 int nthreads);
+/* vector-ark reader for the scoring back end (reference: kaldi_io.read_vec_flt_ark as used by scripts/compute_mean.py:9-33 and
+ * scripts/cosine_score.py:52-60): the whole ark - text 'key [ v0 ... ]' lines as scripts/decode.py:206 writes them, or binary FV / DV
+ * records - into one malloc'ed [n][D] float64 matrix (text values parsed as doubles, as numpy does) and a buffer of n NUL-terminated
+ * keys; parsed on `nthreads` threads.  Free both with spk_vec_ark_free.  0 on success. */
+int spk_vec_ark_load(const char* path, int nthreads, int64_t* n, int32_t* D, double** data, char** keys, int64_t* keys_bytes);
+void spk_vec_ark_free(double* data, char* keys);
+void spk_io_set_error(const char* msg);
 #ifdef __cplusplus
 }
 #endif

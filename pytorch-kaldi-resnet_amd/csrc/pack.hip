@@ -5,7 +5,7 @@
 //                   term s of a weight is the s-th bf16 of its exact three-term split (w = t0 + t1 + t2)
 //   fp16 split    : (split = 3) a 16-byte header - word 0 = float bits of max|w| over the tensor - followed by the same order
 //                   with two terms: w * sigma = h0 + h1 (+ 2^-22 relative), sigma = the power of two that puts max|w| in
-//                   [2^8, 2^9) (spk_sigma_from_amax_bits: the convolution kernels derive the same sigma from the header)
+//                   [2^14, 2^15) (spk_sigma_from_amax_bits: the convolution kernels derive the same sigma from the header)
 // spk_pack_conv_weights_batched packs every convolution of the network in ONE launch from a device-resident job table
 // (the weights change every step, so this runs once per step: 70 tiny launches become one).
 #include "spk_common.h"

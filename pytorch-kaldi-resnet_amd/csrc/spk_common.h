@@ -67,7 +67,7 @@ static __device__ __forceinline__ void split3(f32x4 w, uint2& t0, uint2& t1, uin
     t2.y = pack_bf16x2(q2, q3, r2, r3);
 }
 // ---- fp16 operand splitting ("f16x3" mode): u = v * sigma (sigma a power of two chosen so that the tensor's largest
-// magnitude lands near 2^9) is the sum of two fp16 terms up to 2^-22 |u| (2 x 11 significand bits); a product is formed
+// magnitude lands in [2^14, 2^15): spk_sigma_from_amax_bits) is the sum of two fp16 terms up to 2^-22 |u| (2 x 11 significand bits); a product is formed
 // from the three cross terms h1*g1 + h1*g2 + h2*g1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped h2*g2 is
 // 2^-22 relative) and the accumulator is scaled back by 1 / (sigma_a * sigma_b).  Measured against fp64
 // (tools/probe/split_probe.hip, profiles/r02_split_probe.log): the same error as the native fp32 matrix instruction and

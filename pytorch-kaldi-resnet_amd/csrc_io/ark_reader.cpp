@@ -39,6 +39,7 @@ static void set_err(const char* fmt, ...) {
 }
 
 extern "C" const char* spk_io_last_error(void) { return g_err_shared; }
+extern "C" void spk_io_set_error(const char* msg) { set_err("%s", msg); }      // for the other translation units of libspkio
 
 // file-descriptor cache: arks are few and large, reopen per sample is what the reference pays
 static std::mutex g_fd_mu;

@@ -12,13 +12,17 @@ from . import kaldi_io
 
 
 def read_embeddings(ark_path):
-    """utt -> float64 vector from the text ark written by decode ('utt [ v0 ... ]')."""
-    return {k: v for k, v in kaldi_io.read_vec_flt_ark(ark_path)}
+    """utt -> float64 vector from the ark written by decode (text 'utt [ v0 ... ]' lines or binary FV records): an
+    vecark.EmbTable - a dict like the one kaldi_io.read_vec_flt_ark yields, parsed natively (libspkio), that also carries the
+    [n][D] matrix the vectorised paths below work on."""
+    from . import vecark
+    return vecark.load(ark_path)
 
 
 def compute_mean(ark_path, mean_path=None):
     """float32 mean over all vectors (compute_mean.py builds a FloatTensor and torch.mean's it)."""
-    mat = np.stack([np.asarray(v, dtype=np.float32) for _, v in kaldi_io.read_vec_flt_ark(ark_path)])
+    from . import vecark
+    mat = vecark.load(ark_path).mat.astype(np.float32)
     import torch
     mean = torch.from_numpy(mat).mean(dim=0).numpy()   # same reduction as the reference (torch.mean over rows)
     if mean_path:
@@ -29,9 +33,12 @@ def compute_mean(ark_path, mean_path=None):
 
 def _table(vecs, mean):
     """dict utt -> vector  =>  (key -> row index, float32 [N][D] of mean-subtracted vectors).  The subtraction is done
-    in float64 and cast to float32, as the reference does (numpy float64 ark values minus the mean, then FloatTensor)."""
-    keys = list(vecs)
+    in float64 and cast to float32, as the reference does (numpy float64 ark values minus the mean, then FloatTensor).
+    An EmbTable (read_embeddings) is converted in one vectorised pass over its matrix."""
     m = np.zeros(1) if mean is None else np.asarray(mean, dtype=np.float64)
+    if hasattr(vecs, "mat") and len(vecs) == len(vecs.keys_list):       # (no duplicate keys: dict and matrix agree)
+        return vecs.index, (vecs.mat - m).astype(np.float32)
+    keys = list(vecs)
     mat = np.stack([(np.asarray(vecs[k], dtype=np.float64) - m).astype(np.float32) for k in keys])
     return {k: i for i, k in enumerate(keys)}, mat
 
@@ -50,24 +57,26 @@ def cosine_score(enroll, test, trials_path, mean=None, score_path=None, backend=
         a, b, t = line.strip().split()
         pairs.append((a, b))
         labels.append(1 if t == "target" else 0)
+    ie, me = _table(enroll, mean)
+    it, mt = (ie, me) if test is enroll else _table(test, mean)
+    ia = np.fromiter((ie[a] for a, _ in pairs), dtype=np.int32, count=len(pairs))    # KeyError = unknown utterance
+    ib = np.fromiter((it[b] for _, b in pairs), dtype=np.int32, count=len(pairs))
     if backend == "hip":
         import torch
         from . import ops
-        ie, me = _table(enroll, mean)
-        it, mt = (ie, me) if test is enroll else _table(test, mean)
         en = _device_rows(me, 1e-8)
         te = en if test is enroll else _device_rows(mt, 1e-8)
-        ia = torch.tensor([ie[a] for a, _ in pairs], dtype=torch.int32).cuda()    # KeyError = unknown utterance, as on the host
-        ib = torch.tensor([it[b] for _, b in pairs], dtype=torch.int32).cuda()
-        scores = ops.trial_cosine(en, te, ia, ib).cpu().numpy()
+        scores = ops.trial_cosine(en, te, torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda()).cpu().numpy()
     else:
         assert backend == "host", backend
-        m = np.zeros(1) if mean is None else np.asarray(mean, dtype=np.float64)
-        ea = np.stack([(np.asarray(enroll[a], dtype=np.float64) - m).astype(np.float32) for a, _ in pairs])
-        tb = np.stack([(np.asarray(test[b], dtype=np.float64) - m).astype(np.float32) for _, b in pairs])
-        num = (ea * tb).sum(1, dtype=np.float32)
-        den = np.maximum(np.linalg.norm(ea, axis=1), 1e-8) * np.maximum(np.linalg.norm(tb, axis=1), 1e-8)
-        scores = (num / den).astype(np.float32)
+        # the same arithmetic as before, gathered in chunks so that 10^7 trials do not materialise two [T][D] matrices at once
+        ne = np.maximum(np.linalg.norm(me, axis=1), 1e-8)
+        nt = ne if test is enroll else np.maximum(np.linalg.norm(mt, axis=1), 1e-8)
+        scores = np.empty(len(pairs), dtype=np.float32)
+        for lo in range(0, len(pairs), 1 << 18):
+            ja, jb = ia[lo:lo + (1 << 18)], ib[lo:lo + (1 << 18)]
+            num = (me[ja] * mt[jb]).sum(1, dtype=np.float32)
+            scores[lo:lo + len(ja)] = (num / (ne[ja] * nt[jb])).astype(np.float32)
     if score_path:
         with open(score_path, "w") as f:
             for (a, b), s in zip(pairs, scores):

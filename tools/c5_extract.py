@@ -21,7 +21,10 @@ ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--trials", type=int, default=100000)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--workers", type=int, default=8)
-ap.add_argument("--out-format", default="text")
+ap.add_argument("--out-format", default="text", help="text (the reference's line format) or fv (binary Kaldi float vectors)")
+ap.add_argument("--big-trials", type=int, default=5000000,
+                help="also score N seeded trials in-process on both back ends (no score file: the per-line Python formatting is common "
+                     "to both and would hide the difference) - the size at which the arithmetic, not the file parsing, decides; 0 = skip")
 ap.add_argument("--oracle-subset", type=int, default=2048,
                 help="the CPU oracle (the checker) extracts the first N utterances from the same checkpoint: max 1 - cos against the "
                      "HIP embeddings and the EER of both on 20 k seeded trials inside the subset (SURVEY.md section 8d, C5); 0 = skip")
@@ -76,6 +79,29 @@ res["eer"] = eer.strip().splitlines()[-1]
 _, eer_h = run([py, os.path.join(sc, "compute_eer.py"), os.path.join(a.dir, "scores_host"), os.path.join(a.dir, "trials")])
 res["eer_host_scores"] = eer_h.strip().splitlines()[-1]
 res["trials"] = len(s_d)
+res["out_format"] = a.out_format
+if a.big_trials:
+    # compute-bound size: both back ends in this process on the same table (embeddings parsed once, natively)
+    from pytorch_kaldi_resnet_amd import kaldi_io as _kio, scoring as _sc  # noqa: E402
+    emb_t = _sc.read_embeddings(iv)
+    mean_v = _kio.read_vec_flt(os.path.join(a.dir, "mean.vec"))
+    rs_b = np.random.RandomState(5)
+    names_b = emb_t.keys_list
+    ia_b, ib_b = rs_b.randint(0, len(names_b), a.big_trials), rs_b.randint(0, len(names_b), a.big_trials)
+    big = os.path.join(a.dir, "trials_big")
+    t = time.time()
+    with open(big, "w") as f:
+        f.write("".join("%s %s %s\n" % (names_b[i], names_b[j], "target" if names_b[i][:7] == names_b[j][:7] else "nontarget")
+                        for i, j in zip(ia_b.tolist(), ib_b.tolist())))
+    res["big_trials"] = a.big_trials
+    res["big_trials_write_s"] = round(time.time() - t, 2)
+    _sc.cosine_score(emb_t, emb_t, os.path.join(a.dir, "trials_subset") if os.path.exists(os.path.join(a.dir, "trials_subset"))
+                     else os.path.join(a.dir, "trials"), mean_v, backend="hip")          # device warm-up (context, library load)
+    for backend in ("hip", "host"):
+        t = time.time()
+        sc_b, _ = _sc.cosine_score(emb_t, emb_t, big, mean_v, backend=backend)
+        res["big_trials_cosine_%s_s" % backend] = round(time.time() - t, 2)
+        res["big_trials_score_sum_%s" % backend] = float(np.asarray(sc_b, dtype=np.float64).sum())
 if a.oracle_subset:
     # the checker: CPU oracle on a subset, same checkpoint (oracle/ is test infrastructure: only compared against here)
     from oracle import spk_oracle as O  # noqa: E402
