@@ -143,3 +143,53 @@ def test_variable_chunk_lengths_one_per_batch_same_on_every_rank(tmp_path):
     assert all(s[1] == 12 for s in shapes) and sum(s[0] for s in shapes) == len(ds)
     # a plain int index still means "the dataset's own chunk length"
     assert ds[0][0].shape == (12, 28)
+
+
+def test_vector_ark_loader_matches_the_python_reader(tmp_path):
+    """libspkio's vector-ark loader (the scoring back end's input) against kaldi_io.read_vec_flt_ark - the reference's reader
+    semantics (scripts/kaldi_io.py:238-290): text 'key [ v ... ]' lines as decode writes them parse to the float64 numpy gives,
+    binary FV records come back bit for bit; nan / inf / signed zero / extreme magnitudes included; a ragged or broken ark fails
+    loudly.  The vectorised table path of the scoring back end must give the scores of the per-key dict path."""
+    from pytorch_kaldi_resnet_amd import scoring, vecark
+    rs = np.random.RandomState(3)
+    M = (rs.randn(300, 24) * np.exp(rs.randn(300, 24) * 4)).astype(np.float32)
+    M[0, :7] = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-38, 3e38]
+    keys = ["spk%02d-u%03d" % (i % 7, i) for i in range(len(M))]
+    tpath, bpath = str(tmp_path / "t.iv"), str(tmp_path / "b.iv")
+    open(tpath, "wb").write(ingest.format_text_vectors(keys, M, 3))
+    with open(bpath, "wb") as f:
+        for k, v in zip(keys, M):
+            kaldi_io.write_vec_flt(f, v, key=k)
+    for path in (tpath, bpath):
+        for nt in (1, 5):
+            t = vecark.load(path, nthreads=nt)
+            assert t.keys_list == keys and t.mat.shape == (300, 24) and t.mat.dtype == np.float64
+            ref = list(kaldi_io.read_vec_flt_ark(path))
+            assert [k for k, _ in ref] == keys
+            for i, (_, v) in enumerate(ref):
+                assert np.array_equal(np.asarray(v, dtype=np.float64), t.mat[i], equal_nan=True), (path, i)
+                assert np.array_equal(t[keys[i]], t.mat[i], equal_nan=True)
+    # the reference-written golden file
+    g = vecark.load(os.path.join(ROOT, "tests", "golden", "io", "emb.iv"))
+    for k, v in kaldi_io.read_vec_flt_ark(os.path.join(ROOT, "tests", "golden", "io", "emb.iv")):
+        assert np.array_equal(np.asarray(v, dtype=np.float64), g[k])
+    # errors: ragged rows, garbage, missing file
+    open(str(tmp_path / "ragged.iv"), "w").write("a [ 1.0 2.0 ]\nb [ 1.0 ]\n")
+    open(str(tmp_path / "junk.iv"), "w").write("a [ 1.0 x2 ]\n")
+    for bad in ("ragged.iv", "junk.iv", "nope.iv"):
+        with pytest.raises(RuntimeError):
+            vecark.load(str(tmp_path / bad))
+    # table path == dict path of the scoring back end (host)
+    fin = vecark.load(str(tmp_path / "b.iv"))
+    fin.mat[0, :7] = 0.5
+    names = fin.keys_list
+    tr = str(tmp_path / "trials")
+    with open(tr, "w") as f:
+        for _ in range(500):
+            i, j = rs.randint(0, len(names), 2)
+            f.write("%s %s %s\n" % (names[i], names[j], "target" if names[i][:5] == names[j][:5] else "nontarget"))
+    mean = fin.mat.mean(axis=0)
+    s_tab, l_tab = scoring.cosine_score(fin, fin, tr, mean)
+    plain = {k: np.array(v) for k, v in fin.items()}
+    s_dict, l_dict = scoring.cosine_score(plain, plain, tr, mean)
+    assert np.array_equal(s_tab, s_dict) and np.array_equal(l_tab, l_dict)

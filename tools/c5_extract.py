@@ -106,10 +106,16 @@ if a.oracle_subset:
     # the checker: CPU oracle on a subset, same checkpoint (oracle/ is test infrastructure: only compared against here)
     from oracle import spk_oracle as O  # noqa: E402
     from pytorch_kaldi_resnet_amd import kaldi_io, scoring  # noqa: E402
-    # spread over speakers: every (len // N)-th line
+    # 16 utterances of every k-th speaker (utterance ids are spkNNNN-uttNNNN, speakers contiguous in all.scp): a subset with
+    # target trials in it
     alll = [l.split() for l in open(os.path.join(a.dir, "all.scp"))]
-    step = max(1, len(alll) // a.oracle_subset)
-    sub = alll[::step][:a.oracle_subset]
+    per = min(16, a.utts_per_speaker)
+    nspk_sub = max(1, a.oracle_subset // per)
+    spk_step = max(1, a.speakers // nspk_sub)
+    sub = []
+    for sidx in range(0, a.speakers, spk_step):
+        sub += alll[sidx * a.utts_per_speaker:sidx * a.utts_per_speaker + per]
+    sub = sub[:a.oracle_subset]
     st = {k: v.clone() for k, v in torch.load(ck, map_location="cpu", weights_only=True)["state_dict"].items()}
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t = time.time()
