@@ -124,6 +124,15 @@ struct ConvArgs {
 // weights keep their order: a lane picks its tap's 16-byte piece by address.  Inside a pixel the LDS image is [8-channel
 // half][term] instead of [term][half], and the 16 rows of a tile are a permutation of 16 consecutive pixels (even pixels on rows
 // 4-11): with both, the four 16-lane groups of a ds_read_b128 are conflict-free (the natural order is 2-way).
+#ifdef CONV_STAMPS
+// diagnostic build (tools/variant.sh ... -DCONV_STAMPS): shader-clock stamps of the phases of a block of the non-pipelined split
+// kernel, written by lane 0 of wave 0 to a device array that no other code reads (spk_debug_stamps copies it out)
+#define CONV_STAMP_BLOCKS 4096
+__device__ unsigned long long g_conv_stamps[CONV_STAMP_BLOCKS][16];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < CONV_STAMP_BLOCKS) g_conv_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false, bool M16 = false>
 static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
@@ -221,36 +230,104 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int cout32 = a.Cout >> 5;
     const int quad = tid & (TPP - 1);   // this thread's float4 of channels within a staged pixel
     const int prow = tid / TPP;         // and its pixel slot within a staging pass
-    auto store_pair = [&](float* plane, int p, uint2 t0, uint2 t1) {      // f16x3: the two terms of one float4 of channels
+    auto store_pair_q = [&](float* plane, int p, int qd, uint2 t0, uint2 t1) {      // f16x3: the two terms of float4 `qd` of a plane's channels
         if constexpr (M16) {
-            uint2* dst = (uint2*)plane + p * (LP4 * 2) + (quad >> 1) * 4 + (quad & 1);   // [8-channel half][term][8 ch]
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + (qd >> 1) * 4 + (qd & 1);   // [8-channel half][term][8 ch]
             dst[0] = t0;
             dst[2] = t1;
         } else {
-            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;      // [term][CK ch]: CK*2 bytes per term
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + qd;      // [term][CK ch]: CK*2 bytes per term
             dst[0] = t0;
             dst[CK / 4] = t1;
         }
     };
-    auto store_px = [&](float* plane, int p, f32x4 w) {
+    auto store_px_q = [&](float* plane, int p, int qd, f32x4 w) {
         if constexpr (SPLIT == 0) {
-            *(f32x4*)(plane + p * (LP4 * 4) + quad * 4) = w;
+            *(f32x4*)(plane + p * (LP4 * 4) + qd * 4) = w;
         } else if constexpr (SPLIT == 3) {
             uint2 t0, t1;
             split2h(w, sig, t0, t1);
-            store_pair(plane, p, t0, t1);
+            store_pair_q(plane, p, qd, t0, t1);
         } else {
             uint2 t0, t1, t2;
             split3(w, t0, t1, t2);
-            uint2* dst = (uint2*)plane + p * (LP4 * 2) + quad;   // [term][CK ch]: CK*2 bytes per term
+            uint2* dst = (uint2*)plane + p * (LP4 * 2) + qd;   // [term][CK ch]: CK*2 bytes per term
             dst[0] = t0;
             dst[CK / 4] = t1;
             dst[CK / 2] = t2;
         }
     };
+    auto store_pair = [&](float* plane, int p, uint2 t0, uint2 t1) { store_pair_q(plane, p, quad, t0, t1); };
+    auto store_px = [&](float* plane, int p, f32x4 w) { store_px_q(plane, p, quad, w); };
+
+    // Single-tap (1x1) convolutions stage kc channel planes per barrier.  Plane by plane, a staging pass reads CK channels = 64
+    // bytes of a pixel whose channels sit Cin * 4 bytes apart: every 128-byte line is touched by two to eight separate
+    // wave-instructions and the texture-address path, not HBM, sets the pace (in-kernel stamps, profiles/r04_conv_stamps.log: the
+    // two staging phases are 66 % of a block's life on the 128-channel 1x1 convolutions of ResNet-101).  The wide form below maps
+    // the threads across ALL kc planes of a pixel: kc * CK consecutive channels = 256 contiguous bytes per pixel in the f16x3 mode,
+    // 16 lanes each, so a wave-instruction reads four whole pixels; the thread's float4 goes to the plane it belongs to.
+    auto stage_chunk_wide = [&](int ch) {
+        const int tppk = TPP * a.kc;                      // threads per pixel across the planes (kc is 2 or 4: a power of two)
+        const int qk = tid & (tppk - 1);
+        const int pl = qk / TPP, qd = qk & (TPP - 1);
+        const int prowk = tid / tppk, pppk = 256 / tppk;
+        const int c = (ch * a.kc + pl) * CK + qd * 4;
+        float* ldsp = lds + pl * plane_floats;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (flags & SPK_IN_AFFINE_RELU) {
+            sc = *(const f32x4*)(a.in_scale + c);
+            sh = *(const f32x4*)(a.in_shift + c);
+        }
+        constexpr int U = STAGE_U;
+        for (int base = prowk; base < halo_pix; base += pppk * U) {
+            f32x4 v[U];
+            bool inb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int p = base + pppk * u;
+                p = p < halo_pix ? p : halo_pix - 1;
+                const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+                const int hx = p - hy * a.halo_w;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                inb[u] = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+                const unsigned pi = inb[u] ? (unsigned)((iy * a.IWp + ix) * a.ips) : pi_safe_p;
+                v[u] = *(const f32x4*)(img_in_p + pi * (unsigned)a.Cin + (unsigned)c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = base + pppk * u;
+                f32x4 w = v[u];
+                if (flags & SPK_IN_AFFINE_RELU) {
+                    w = w * sc + sh;
+                    w[0] = fmaxf(w[0], 0.f);
+                    w[1] = fmaxf(w[1], 0.f);
+                    w[2] = fmaxf(w[2], 0.f);
+                    w[3] = fmaxf(w[3], 0.f);
+                }
+                if (!inb[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT == 3) {
+                    if (flags & SPK_IN_PRESPLIT) {           // f16 pair tensor: the 16 bytes ARE the two terms
+                        uint2 t0, t1;
+                        spk_pair_unpack(w, t0, t1);
+                        if (p < halo_pix) store_pair_q(ldsp, p, qd, t0, t1);
+                        continue;
+                    }
+                }
+                if (p < halo_pix) store_px_q(ldsp, p, qd, w);
+            }
+        }
+    };
 
     // stage the kc channel planes of chunk `ch` (global -> registers -> fused input transform -> LDS)
     auto stage_chunk = [&](int ch) {
+        if constexpr (!BNBWD && !PIPE) {
+#ifndef CONV_NO_WIDE_STAGE
+            if (a.kc > 1) {
+                stage_chunk_wide(ch);
+                return;
+            }
+#endif
+        }
         for (int pl = 0; pl < a.kc; ++pl) {
             const int c = (ch * a.kc + pl) * CK + quad * 4;
             float* ldsp = lds + pl * plane_floats;
@@ -949,9 +1026,13 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 load_b(b0, a.tap_w[0], a.tap_g[0]);
+                if (ch == 0) STAMP(0);
                 __syncthreads();  // every wave is done reading the previous chunk's tile
+                if (ch < 2) STAMP(1 + 4 * ch);
                 stage_chunk(ch);
+                if (ch < 2) STAMP(2 + 4 * ch);
                 __syncthreads();
+                if (ch < 2) STAMP(3 + 4 * ch);
                 load_b(b1, a.tap_w[min(1, last)], a.tap_g[min(1, last)]);   // (after staging: its registers are busy there)
                 load_a(aq, a.tap_off[0], 0);
                 int o1 = a.tap_off[min(1, last)], w2 = a.tap_w[min(2, last)], g2 = a.tap_g[min(2, last)];
@@ -972,6 +1053,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     step(b0, b2, o1, w2, g2);
                     if (t + 1 < a.ntaps) step(b1, b0, a.tap_off[last], a.tap_w[last], a.tap_g[last]);
                 }
+                if (ch < 2) STAMP(4 + 4 * ch);
             }
         }
     }
@@ -1221,6 +1303,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             }
         }
     }
+    STAMP(9);
     // absmax of what this launch stored (the scale of the next f16x3 consumer of the tensor): one atomicMax per wave
     if (a.out_amax) spk_wave_amax_commit(out_mx, a.out_amax);
     if constexpr (BNBWD) {
@@ -1246,6 +1329,14 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 
 template <int MT, int NT, bool BNBWD, int SPLIT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+#ifdef MFMA_STAGGER
+    // experiment: the blocks a CU holds start together and move through load / convert / compute / store in lockstep; spread the
+    // first round of blocks by their wave slot
+    if (blockIdx.x < 2048u) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID, bits 3:0 = wave slot
+        for (unsigned i = 0; i < (hw & 7u) * MFMA_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     conv_body<MT, NT, BNBWD, SPLIT, false>(a);
 }
 

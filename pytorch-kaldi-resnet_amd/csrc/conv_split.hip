@@ -26,3 +26,10 @@ int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, i
     spk_set_error("spk_conv_mfma: unsupported split tile config MT=%d NT=%d", MT, NT);
     return -1;
 }
+
+#ifdef CONV_STAMPS
+extern "C" int spk_debug_stamps(unsigned long long* out, int nblocks) {     // diagnostic builds only (never in the in-tree library)
+    if (nblocks > CONV_STAMP_BLOCKS) nblocks = CONV_STAMP_BLOCKS;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

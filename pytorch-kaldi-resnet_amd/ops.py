@@ -181,6 +181,8 @@ def _experimental():
 
 
 SPLIT_1X1 = os.environ.get("SPK_SPLIT_1X1", "1") == "1"
+# channel planes a single-tap (1x1) convolution stages per barrier: the first candidate that divides the channels and fits LDS
+KC_CANDIDATES = tuple(int(v) for v in os.environ.get("SPK_KC", "4,2").split(","))
 
 
 def split_for(ksize, bwd=False):
@@ -282,7 +284,7 @@ def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, e
     kc = 1
     if len(taps) == 1:
         halo = ((TH - 1) * IS + 1) * ((TW - 1) * IS + 1)
-        for cand in (4, 2):
+        for cand in KC_CANDIDATES:
             if Cin % (32 * cand) == 0 and cand * halo * tiling.LDS_PIX_BYTES <= tiling.LDS_HARD:
                 kc = cand
                 break
