@@ -1329,14 +1329,6 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 
 template <int MT, int NT, bool BNBWD, int SPLIT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-#ifdef MFMA_STAGGER
-    // experiment: the blocks a CU holds start together and move through load / convert / compute / store in lockstep; spread the
-    // first round of blocks by their wave slot
-    if (blockIdx.x < 2048u) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID, bits 3:0 = wave slot
-        for (unsigned i = 0; i < (hw & 7u) * MFMA_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     conv_body<MT, NT, BNBWD, SPLIT, false>(a);
 }
 

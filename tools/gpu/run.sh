@@ -7,6 +7,7 @@
 #   bench            default bench line            bench_forced   the same under SPK_FORCE_REDUCER=1 (RCCL, one rank)
 #   bench_ingest / bench_c4 / bench_c5 / bench_fast (no CPU legs)
 #   smoke            __graft_entry__.smoke()
+#   gpus2_gloo       `python bench.py --gpus 2` spawning its own two ranks, both on GPU 0 over gloo (control-flow rehearsal, not a measurement)
 #   profile          tools/profile_bench.sh (kernel trace + FETCH / WRITE passes)      profile_sq   tools/profile_sq.sh
 #   trace_forced     rocprofv3 --kernel-trace --stats of the forced-reducer bench (RCCL kernel names)
 #   py:<script> [args are not supported: wrap them in a tools/ script]
@@ -37,6 +38,7 @@ for step in "$@"; do
         bench_c4)      run bench_c4 400 python3 bench.py --config c4 --steps 16 --warmup 8 --no-cpu-baseline --no-eer ;;
         bench_c5)      run bench_c5 300 python3 bench.py --config c5 --steps 20 --warmup 5 ;;
         smoke)         run smoke 200 python3 __graft_entry__.py smoke ;;
+        gpus2_gloo)    SPK_FORCE_DEVICE=0 SPK_DIST_BACKEND=gloo run gpus2_gloo 300 python3 bench.py --gpus 2 --batch 64 --steps 5 --warmup 2 $FAST --no-roofline --no-extra ;;
         profile)       run profile 600 bash tools/profile_bench.sh $D/prof ;;
         profile_sq)    run profile_sq 400 bash tools/profile_sq.sh $D/sq ;;
         profile_sq2)   run profile_sq2 500 bash tools/profile_sq2.sh $D/sq2 ;;
