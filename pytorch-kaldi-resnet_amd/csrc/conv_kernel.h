@@ -128,7 +128,7 @@ struct ConvArgs {
 // diagnostic build (tools/variant.sh ... -DCONV_STAMPS): shader-clock stamps of the phases of a block of the non-pipelined split
 // kernel, written by lane 0 of wave 0 to a device array that no other code reads (spk_debug_stamps copies it out)
 #define CONV_STAMP_BLOCKS 4096
-__device__ unsigned long long g_conv_stamps[CONV_STAMP_BLOCKS][16];
+static __device__ unsigned long long g_conv_stamps[CONV_STAMP_BLOCKS][16];      // (one copy per translation unit)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < CONV_STAMP_BLOCKS) g_conv_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -599,9 +599,13 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         // offsets of a unit (plane c, tap t): A in LDS (16-byte units), B in the packed weights (floats)
         auto ao = [&](int slot, int t) { return slot * plane4 + a.tap_off[t]; };
         auto bo = [&](int c, int t) { return a.tap_w[t] * tap_stride + c * grp_stride; };
+        STAMP(0);
         __syncthreads();
+        STAMP(1);
         stage_chunk(0);                      // first plane: staged the plain way into slot 0
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
         // (per-lane offsets of a step: formed where they are used - nine of them held across the loop cost nine registers)
 #define O0 sel(ao(0, 0), ao(0, 1))
 #define O1 sel(ao(0, 2), ao(0, 3))
@@ -652,6 +656,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 #pragma unroll
                 for (int j = 0; j < AN; ++j) bx[s2][j] = by[s2][j];
         }
+        STAMP(4);
 #undef O0
 #undef O1
 #undef O2

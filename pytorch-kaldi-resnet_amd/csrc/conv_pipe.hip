@@ -46,3 +46,15 @@ int spk_launch_conv_pipe(const ConvArgs& a, size_t lds_bytes, int MT, int NT, hi
     spk_set_error("spk_conv_mfma: unsupported pipelined tile config MT=%d NT=%d", MT, NT);
     return -1;
 }
+
+#ifdef CONV_STAMPS
+extern "C" int spk_debug_stamps_pipe(unsigned long long* out, int nblocks) {     // diagnostic builds only (never in the in-tree library)
+    if (nblocks < 0) {        // reset
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_stamps)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * 16 * CONV_STAMP_BLOCKS);
+    }
+    if (nblocks > CONV_STAMP_BLOCKS) nblocks = CONV_STAMP_BLOCKS;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

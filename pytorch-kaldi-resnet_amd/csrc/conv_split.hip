@@ -29,6 +29,11 @@ int spk_launch_conv_split(const ConvArgs& a, size_t lds_bytes, int MT, int NT, i
 
 #ifdef CONV_STAMPS
 extern "C" int spk_debug_stamps(unsigned long long* out, int nblocks) {     // diagnostic builds only (never in the in-tree library)
+    if (nblocks < 0) {        // reset
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_stamps)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * 16 * CONV_STAMP_BLOCKS);
+    }
     if (nblocks > CONV_STAMP_BLOCKS) nblocks = CONV_STAMP_BLOCKS;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }

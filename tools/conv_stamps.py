@@ -17,11 +17,15 @@ from pytorch_kaldi_resnet_amd import hip, ops  # noqa: E402
 
 B = int(os.environ.get("B", "256"))
 cases = {"l1": (32, 32, 80, 300, 3, 1), "c128_1x1": (128, 128, 20, 75, 1, 1), "c64_1x1": (64, 64, 40, 150, 1, 1),
-         "s2": (32, 64, 80, 300, 3, 2)}
+         "s2": (32, 64, 80, 300, 3, 2),
+         # the pipelined kernel (a second diagnostic library: tools/variant.sh stamps_pipe conv_pipe.hip -DCONV_STAMPS)
+         "c64_3x3": (64, 64, 40, 150, 3, 1), "c128_3x3": (128, 128, 20, 75, 3, 1), "c256_3x3": (256, 256, 10, 38, 3, 1)}
 lib = hip.lib()
-lib.spk_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+PIPE = any(n.endswith("_3x3") for n in sys.argv[1:])
+reader = lib.spk_debug_stamps_pipe if PIPE else lib.spk_debug_stamps
+reader.argtypes = [ctypes.c_void_p, ctypes.c_int]
 NB = 4096
-for name in sys.argv[1:] or list(cases):
+for name in sys.argv[1:] or [c for c in cases if not c.endswith("_3x3")]:
     Cin, Cout, H, W, k, stride = cases[name]
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
@@ -30,17 +34,24 @@ for name in sys.argv[1:] or list(cases):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for i in range(4):
         if i == 3:
+            torch.cuda.synchronize()
+            assert reader(None, -1) == 0           # zero the stamp array: only the blocks of the launch below are read back
             e0.record()
         out, st = ops.conv_fwd(x, wpk, Cout, k, stride, in_affine=aff, stats=True)
     e1.record()
     torch.cuda.synchronize()
     buf = np.zeros((NB, 16), dtype=np.uint64)
-    rc = lib.spk_debug_stamps(buf.ctypes.data, NB)
+    rc = reader(buf.ctypes.data, NB)
     assert rc == 0, rc
     s = buf.astype(np.int64)
     ok = s[:, 9] > s[:, 0]
     s = s[ok]
     d = lambda i, j: float(np.mean(s[:, i] - s[:, j]))      # noqa: E731
+    if PIPE:
+        print("%s: %d x %d x %d -> %d ch, 3x3 pipelined: launch %.3f ms, %d blocks stamped" % (name, H, W, Cin, Cout, e0.elapsed_time(e1), len(s)))
+        print("   first barrier %6.0f   first plane staged the plain way %8.0f   barrier %6.0f   K loop (in-loop staging) %8.0f   epilogue %8.0f   "
+              "block lifetime %8.0f cyc" % (d(1, 0), d(2, 1), d(3, 2), d(4, 3), d(9, 4), d(9, 0)))
+        continue
     two = bool((s[:, 5] > 0).all())
     print("%s: %d x %d x %d -> %d ch, %dx%d stride %d: launch %.3f ms, %d blocks stamped" % (name, H, W, Cin, Cout, k, k, stride,
                                                                                        e0.elapsed_time(e1), len(s)))
