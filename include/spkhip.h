@@ -130,6 +130,22 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
  * the kernel's register prefetch window: halo pixels <= *max_halo_pix, TH*TW <= *max_tile_pix (spk_conv_wgrad_limits). */
 int spk_conv_wgrad_limits(int WN, int* max_halo_pix /*host*/, int* max_tile_pix /*host*/);
 size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
+/* Streaming 1x1 convolution, C -> C channels (C = 32, 64 or 128), stride 1, f16x3 operands: forward and data gradient of the 1x1
+ * convolutions of the Bottleneck blocks (scripts/model.py:104-110,118-126) - a GEMM [P pixels][C] x [C][C] by persistent blocks that
+ * keep the whole weight matrix in registers, stage every pixel once (whole 128-byte lines; fused BatchNorm + ReLU with
+ * SPK_IN_AFFINE_RELU, plain copy of an f16 pair tensor with SPK_IN_PRESPLIT) and store from the accumulator layout.  in / out /
+ * epi_add / bn_raw: [P][C]; wpk: spk_pack_conv_weight_split(split = 3) of the 1x1 weights (transpose = 1 for the data gradient);
+ * flags: SPK_IN_AFFINE_RELU | SPK_IN_PRESPLIT | SPK_EPI_STATS | SPK_EPI_ADD (+ add_mask: add only where the bit is set) |
+ * SPK_EPI_BNBWD (statistics of the BatchNorm-backward of bn4 = [mean, invstd, scale, shift][C] over dz = out * mask, mask = the
+ * bits of bn_mask, or bn_raw * scale + shift > 0 when bn_mask is NULL).  stats: [spk_conv1x1_stream_rows(nblocks, C)][C][2]
+ * partial rows for spk_bn_finalize / spk_bn_bwd_finalize.  in_amax: REQUIRED (slot of the staged values, as spk_conv_mfma);
+ * out_amax: optional.  nblocks: persistent blocks (<= tiles of 64 / 128 / 256 pixels at C = 128 / 64 / 32; two per CU is the
+ * measured choice).  Same arithmetic as spk_conv_mfma on these launches; another summation order of the statistics partials. */
+int spk_conv1x1_stream(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift,
+                       const float* epi_add, const unsigned* add_mask, const float* bn_raw, const unsigned* bn_mask,
+                       const float* bn4, float* stats, long long P, int C, int flags, const unsigned* in_amax, unsigned* out_amax,
+                       int nblocks, void* stream);
+int spk_conv1x1_stream_rows(int nblocks, int C);
 /* spk_conv_wgrad writes nsplit partial slabs [nsplit][k*k][Cin][Cout] (nsplit <= number of pixel regions); spk_wgrad_reduce
  * sums them in a fixed order into dw (OIHW), optionally accumulating.  (`dw`/`accumulate` of spk_conv_wgrad are unused.) */
 int spk_wgrad_reduce(const float* partial, float* dw, int nslab, int ksize, int Cin, int Cout, int accumulate, void* stream);

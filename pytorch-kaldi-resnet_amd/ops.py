@@ -249,11 +249,60 @@ class PackTable:
              label="spk_pack_conv_weight")
 
 
+STREAM_1X1 = os.environ.get("SPK_STREAM_1X1", "1") == "1"
+STREAM_1X1_BLOCKS = int(os.environ.get("SPK_STREAM_1X1_BLOCKS", "512"))       # persistent blocks: two per CU
+
+
+def _conv1x1_stream(x, wpk, out, in_affine, epi_add, add_mask, bn_bwd, want_stats, in_amax, out_amax, in_presplit):
+    B, H, W, C = x.shape
+    P = B * H * W
+    tp = 64 * (1 if C >= 128 else (2 if C == 64 else 4))
+    nblocks = max(1, min(STREAM_1X1_BLOCKS, -(-P // tp)))
+    flags = 0
+    if in_affine is not None:
+        flags |= IN_AFFINE_RELU
+    if in_presplit:
+        assert in_affine is None
+        flags |= IN_PRESPLIT
+    if epi_add is not None:
+        assert epi_add.shape == out.shape
+        flags |= EPI_ADD
+    bn_mask = bn_bwd[3] if (bn_bwd is not None and len(bn_bwd) > 3) else None
+    for mk in (bn_mask, add_mask):
+        if mk is not None:
+            assert mk.dtype == torch.int32 and mk.numel() == out.numel() // 32, "sign mask shape"
+    stats = None
+    if bn_bwd is not None:
+        want_stats = True
+        flags |= EPI_BNBWD
+        assert bn_bwd[0].shape == out.shape
+    if want_stats:
+        flags |= EPI_STATS
+        stats = torch.empty(hip.lib().spk_conv1x1_stream_rows(nblocks, C), C, 2, device=x.device, dtype=torch.float32)
+    call("spk_conv1x1_stream", ptr(x), ptr(wpk), ptr(out), ptr(in_affine[0]) if in_affine else None,
+         ptr(in_affine[1]) if in_affine else None, ptr(epi_add), ptr(add_mask), ptr(bn_bwd[0]) if bn_bwd else None, ptr(bn_mask),
+         ptr(bn_bwd[2]) if bn_bwd else None, ptr(stats), P, C, flags, ptr(in_amax), ptr(out_amax), nblocks, stream(),
+         label="conv1x1_stream_kernel<%d>" % C + (" C%d %dx%d" % (C, H, W) if LABEL_SHAPES else ""),
+         flops=2.0 * P * C * C,
+         nbytes=4.0 * (P * C * (2 + (1 if epi_add is not None else 0) + (1 if bn_bwd is not None else 0))
+                       + (P * C / 32) * ((bn_mask is not None) + (add_mask is not None)) + wpk.numel()))
+    return stats
+
+
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
                  bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None, in_amax=None, out_amax=None, side_amax=None,
                  in_presplit=False, side_presplit=False):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
+    # Streaming 1x1 kernel (csrc/conv1x1_stream.hip): C -> C channels at stride 1 in the f16x3 mode, training-mode epilogues only
+    # (raw output + statistics; data gradients: shortcut add with or without its sign mask, BatchNorm-backward statistics with the
+    # mask as sign bits or recomputed from the raw tensor).  Everything else - eval-mode epilogues, strided 1x1, other widths,
+    # the fused input BatchNorm backward, an activation tensor as the mask - stays on the general kernel.
+    if (STREAM_1X1 and split == 3 and len(taps) == 1 and taps[0][0] == 0 and taps[0][1] == 0 and IS == 1 and OS == 1 and ooy == 0
+            and oox == 0 and Cin == Cout and Cin in (32, 64, 128) and (IH, IW) == (OH, OW) == (OHf, OWf) and in_bnbwd is None
+            and side is None and epi_affine is None and not relu and not side_presplit and out is not x
+            and (bn_bwd is None or bn_bwd[1] is None or len(bn_bwd) > 3) and B * OH * OW * Cin < 2 ** 31):
+        return _conv1x1_stream(x, wpk, out, in_affine, epi_add, add_mask, bn_bwd, want_stats, in_amax, out_amax, in_presplit)
     dys = [t[0] for t in taps]
     dxs = [t[1] for t in taps]
     tws = [t[2] for t in taps]

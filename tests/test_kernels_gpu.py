@@ -70,6 +70,10 @@ CONV_CASES = [
     (1, 256, 256, 5, 3, 3, 1),
     (2, 128, 256, 10, 19, 1, 2),    # 1x1: four input-channel groups per block (conv_wgrad_1x1_kernel), strided
     (2, 256, 64, 9, 11, 1, 1),
+    # C -> C at stride 1: the streaming 1x1 kernel (conv1x1_stream.hip), with a ragged last tile each
+    (2, 128, 128, 20, 75, 1, 1),
+    (3, 32, 32, 13, 11, 1, 1),
+    (1, 64, 64, 40, 150, 1, 1),
 ]
 
 
@@ -870,3 +874,74 @@ def test_experimental_kernel_forms_in_their_variant_library():
     import re
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 30, tail                  # 28 + 5 + 6 cases; a few layouts skip themselves by design
+
+
+
+@pytest.mark.parametrize("C,B,H,Wd", [(128, 5, 20, 75), (64, 3, 33, 41), (32, 2, 47, 53), (128, 1, 3, 5)])
+def test_streaming_1x1_kernel_equals_the_general_kernel(ops, C, B, H, Wd):
+    """conv1x1_stream_kernel (persistent blocks, weights in registers, every pixel staged once, stores from the accumulator layout)
+    against conv_mfma_kernel on the same launches - the 1x1 convolutions of the Bottleneck blocks (reference scripts/model.py:
+    104-110,118-126), forward and data gradient with every epilogue the engine uses there.  Same operands (two fp16 terms under
+    the same slot), same products; the accumulation order inside the matrix instruction chain differs (K in one pass here), so
+    outputs agree to fp32 accumulation error (2e-6 of the output range), not bit for bit; the statistics partials sum to the same
+    totals (1e-5: fp32 partial rows of different lengths).  Grids of 1, 7 and the default number of persistent blocks."""
+    if ops.SPLIT != 3:
+        pytest.skip("the streaming kernel exists for the f16x3 operand mode")
+    x = rnd(31, B, C, H, Wd, scale=1.5, shift=0.2)
+    w = rnd(32, C, C, 1, 1, scale=0.2)
+    xg = nhwc(x)
+    wpk, wpk_t = ops.pack_conv_weight(w.cuda()), ops.pack_conv_weight(w.cuda(), transpose=True)
+    isc, ish = rnd(33, C, scale=0.5, shift=1.0).cuda(), rnd(34, C, scale=0.3).cuda()
+    dy = nhwc(rnd(35, B, C, H, Wd, scale=1e-3))
+    addt = nhwc(rnd(36, B, C, H, Wd, scale=1e-3))
+    gate = rnd(37, B, C, H, Wd)
+    rawt = nhwc(rnd(38, B, C, H, Wd, scale=2.0, shift=0.3))
+    bn4 = torch.stack([rnd(39, C, scale=0.3), rnd(40, C, scale=0.2, shift=1.0), rnd(41, C, scale=0.5, shift=1.0), rnd(42, C, scale=0.4)]).cuda()
+    # an f16 pair tensor of dy under a slot holding a bound of it (what bn_bwd_apply(pair_scale=) produces)
+    slot = ops.absmax_into(dy, torch.zeros(1, device="cuda", dtype=torch.int32))
+    amax = float(slot.view(torch.float32))
+    sig = 2.0 ** (14 - int(np.floor(np.log2(amax))))
+    v = dy.cpu().float() * sig
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    pairs = torch.stack([hi.view(-1, 4), lo.view(-1, 4)], dim=1).contiguous().view(torch.float32).view(dy.shape).cuda()
+
+    def run(stream, blocks):
+        old = ops.STREAM_1X1, ops.STREAM_1X1_BLOCKS
+        ops.STREAM_1X1, ops.STREAM_1X1_BLOCKS = stream, blocks
+        try:
+            r = {}
+            r["fwd"], r["fwd_st"] = ops.conv_fwd(xg, wpk, C, 1, 1, stats=True)
+            r["aff"], r["aff_st"] = ops.conv_fwd(xg, wpk, C, 1, 1, in_affine=(isc, ish), stats=True)
+            r["dx"] = ops.conv_dgrad(dy, wpk_t, C, 1, 1, (H, Wd), in_amax=slot)
+            r["dx_pair"] = ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), in_amax=slot, in_presplit=True)
+            r["dx_add"] = ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), add=addt, add_mask=sign_mask(gate), in_amax=slot, in_presplit=True)
+            r["dx_bnb"], r["bnb_st"] = ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), add=addt, add_mask=sign_mask(gate),
+                                                      bn_bwd=(rawt, None, bn4, sign_mask(gate)), in_amax=slot, in_presplit=True)
+            r["dx_bnr"], r["bnr_st"] = ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), bn_bwd=(rawt, None, bn4), in_amax=slot, in_presplit=True)
+            acc = addt.clone()
+            ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), out=acc, accumulate=True, in_amax=slot, in_presplit=True)
+            r["dx_acc"] = acc
+            amx = torch.zeros(1, device="cuda", dtype=torch.int32)
+            ops.conv_dgrad(pairs, wpk_t, C, 1, 1, (H, Wd), in_amax=slot, in_presplit=True, out_amax=amx)
+            r["amax"] = amx.view(torch.float32).clone()
+            torch.cuda.synchronize()
+            return r
+        finally:
+            ops.STREAM_1X1, ops.STREAM_1X1_BLOCKS = old
+
+    ref = run(False, 512)
+    assert torch.equal(ref["dx"], ref["dx_pair"])                     # (the pair tensor IS the staged form of dy)
+    for blocks in (1, 7, 512):
+        got = run(True, blocks)
+        for k in ("fwd", "aff", "dx", "dx_pair", "dx_add", "dx_bnb", "dx_bnr", "dx_acc"):
+            scale = float(ref[k].abs().max())
+            assert float((got[k] - ref[k]).abs().max()) <= 2e-6 * scale, (k, blocks)
+        assert torch.equal(got["dx"], got["dx_pair"])
+        assert abs(float(got["amax"]) - float(ref["amax"])) <= 2e-6 * float(ref["amax"])
+        for k in ("fwd_st", "aff_st", "bnb_st", "bnr_st"):
+            a, b = got[k].double().sum(0), ref[k].double().sum(0)
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (k, blocks)
+    # and against the definition (torch CPU fp32)
+    refc = F.conv2d(x, w)
+    assert relerr(nchw(run(True, 512)["fwd"]), refc) < 2e-5
