@@ -133,7 +133,13 @@ static __device__ unsigned long long g_conv_stamps[CONV_STAMP_BLOCKS][16];      
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false, bool M16 = false>
+// FL >= 0: the launch's flag word is a compile-time constant (the SPK_* bits the kernel sees, plus SPK_FL_ADDMASK / SPK_FL_BNMASK:
+// a sign mask accompanies the shortcut add / the BatchNorm-backward statistics; no activation tensor as the statistics' mask) - the
+// epilogue and staging branches fold away.  FL < 0: everything is read from the argument block (any combination).
+#define SPK_FL_ADDMASK (1 << 20)
+#define SPK_FL_BNMASK (1 << 21)
+#define SPK_FL_INMASK (1 << 22)      // fused input BatchNorm backward: its ReLU mask as sign bits (else recomputed from the raw tensor); no side_dz
+template <int MT, int NT, bool BNBWD, int SPLIT, bool PIPE, bool BITS = false, bool PRE = false, bool M16 = false, int FL = -1>
 static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     using Cfg = ConvCfg<SPLIT>;
     constexpr int CK = Cfg::CK, TPP = Cfg::TPP, PPP = Cfg::PPP, LP4 = Cfg::LP4, NTERM = Cfg::NTERM;
@@ -187,7 +193,13 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     float* img_dz = (BNBWD && a.side_dz) ? a.side_dz + img_el : nullptr;
     const int npix_tile = a.TH * a.TW;
     const int n0 = cg * NT * 32;
-    const int flags = a.flags;
+    const int flags = FL >= 0 ? (FL & 0xFFFFF) : a.flags;
+    const bool has_add_mask = FL >= 0 ? (FL & SPK_FL_ADDMASK) != 0 : a.add_mask != nullptr;
+    const bool has_bn_mask = FL >= 0 ? (FL & SPK_FL_BNMASK) != 0 : a.bn_mask != nullptr;
+    const bool has_bn_act = FL >= 0 ? false : a.bn_act != nullptr;
+    const bool has_in_mask = FL >= 0 ? (FL & SPK_FL_INMASK) != 0 : a.in_mask != nullptr;
+    const bool has_in_act = FL >= 0 ? false : a.in_act != nullptr;
+    const bool has_side_dz = FL >= 0 ? false : a.side_dz != nullptr;
 
     int lbase[M16 ? 2 * MT : MT], obase[MT], opix[MT];      // opix: output pixel index (the masks are addressed per pixel)
 #pragma unroll
@@ -366,19 +378,19 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         off[u] = pi * (unsigned)a.Cin + (unsigned)c;
                         v[u] = conv_ld<4>(img_in + off[u]);
                         rw[u] = conv_ld<4>(img_raw + off[u]);
-                        if (a.in_mask) mw[u] = img_mask[pi * (unsigned)(a.Cin >> 5) + (unsigned)(c >> 5)];
-                        else if (a.in_act) ac[u] = *(const f32x4*)(img_act + off[u]);
+                        if (has_in_mask) mw[u] = img_mask[pi * (unsigned)(a.Cin >> 5) + (unsigned)(c >> 5)];
+                        else if (has_in_act) ac[u] = *(const f32x4*)(img_act + off[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < U2; ++u) {
                         const int p = base + PPP * u;
                         f32x4 dz;
-                        if (a.in_mask) {
+                        if (has_in_mask) {
                             const unsigned bits = mw[u] >> (c & 31);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) dz[k] = ((bits >> k) & 1u) ? v[u][k] : 0.f;
                         } else {
-                            const f32x4 m = a.in_act ? ac[u] : rw[u] * bsc + bsh;
+                            const f32x4 m = has_in_act ? ac[u] : rw[u] * bsc + bsh;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) dz[k] = m[k] > 0.f ? v[u][k] : 0.f;
                         }
@@ -396,7 +408,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                                 store_px(ldsp, p, w);
                             if (owner && core[u]) {
                                 conv_st(img_draw + off[u], side);
-                                if (a.side_dz) conv_st(img_dz + off[u], dz);
+                                if (has_side_dz) conv_st(img_dz + off[u], dz);
                                 side_mx = fmaxf(fmaxf(side_mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                             }
                         }
@@ -1141,7 +1153,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     if (flags & SPK_EPI_AFFINE) v = v * es + eh;
                     if (flags & SPK_EPI_ADD) {
                         f32x4 ad = *(const f32x4*)(a.epi_add + ob + qc * 4);
-                        if (a.add_mask) {
+                        if (has_add_mask) {
                             const int ch0 = n0 + qc * 4;
                             const unsigned bits = a.add_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
 #pragma unroll
@@ -1162,23 +1174,23 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         // its backward needs no separate reduction pass over this tensor
                         const f32x4 rw = *(const f32x4*)(a.bn_raw + ob + qc * 4);
                         f32x4 dz;
-                        if (a.bn_mask) {
+                        if (has_bn_mask) {
                             const int ch0 = n0 + qc * 4;
                             const unsigned bits = a.bn_mask[(size_t)((ob - n0) / a.Cout) * (a.Cout >> 5) + (ch0 >> 5)] >> (ch0 & 31);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
                         } else {
                             f32x4 m;
-                            if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
+                            if (has_bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);
                             else m = rw * bsc + bsh;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
                         }
                         ssum += dz;
-                        ssq += dz * ((rw - bmu) * bis);
+                        { const f32x4 xh_ = (rw - bmu) * bis; for (int c_ = 0; c_ < 4; ++c_) ssq[c_] = __builtin_fmaf(dz[c_], xh_[c_], ssq[c_]); }
                     } else {
                         ssum += v;
-                        ssq += v * v;
+                        for (int c_ = 0; c_ < 4; ++c_) ssq[c_] = __builtin_fmaf(v[c_], v[c_], ssq[c_]);      // (explicit: the same rounding in every instantiation)
                     }
                 }
             }
@@ -1224,7 +1236,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         conv_st(a.out + ob + qc * 4, v);
                         out_mx = fmaxf(fmaxf(out_mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         ssum += v;
-                        ssq += v * v;
+                        for (int c_ = 0; c_ < 4; ++c_) ssq[c_] = __builtin_fmaf(v[c_], v[c_], ssq[c_]);      // (explicit: the same rounding in every instantiation)
                     }
                 }
                 continue;
@@ -1244,11 +1256,11 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                     const int o = pix * a.Cout + ch0;                                     // element offset of this lane's quad
                     if (f_add) {
                         adv[kk] = conv_ld<2>(a.epi_add + o);
-                        if (a.add_mask) amw[kk] = a.add_mask[(size_t)pix * cw32 + (ch0 >> 5)];
+                        if (has_add_mask) amw[kk] = a.add_mask[(size_t)pix * cw32 + (ch0 >> 5)];
                     }
                     if (f_bnb) {
                         rwv[kk] = conv_ld<2>(a.bn_raw + o);
-                        if (a.bn_mask) bmw[kk] = a.bn_mask[(size_t)pix * cw32 + (ch0 >> 5)];
+                        if (has_bn_mask) bmw[kk] = a.bn_mask[(size_t)pix * cw32 + (ch0 >> 5)];
                     }
                 }
 #pragma unroll
@@ -1266,7 +1278,7 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                         if (flags & SPK_EPI_AFFINE) v = v * es + eh;
                         if (f_add) {
                             f32x4 ad = adv[kk];
-                            if (a.add_mask) {
+                            if (has_add_mask) {
                                 const unsigned bits = amw[kk] >> (ch0 & 31);
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) ad[c] = ((bits >> c) & 1u) ? ad[c] : 0.f;
@@ -1286,22 +1298,22 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
                             // its backward needs no separate reduction pass over this tensor
                             const f32x4 rw = rwv[kk];
                             f32x4 dz;
-                            if (a.bn_mask) {
+                            if (has_bn_mask) {
                                 const unsigned bits = bmw[kk] >> (ch0 & 31);
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) dz[c] = ((bits >> c) & 1u) ? v[c] : 0.f;
                             } else {
                                 f32x4 m;
-                                if (a.bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);      // (activated tensor instead of mask bits: tests / tools)
+                                if (has_bn_act) m = *(const f32x4*)(a.bn_act + ob + qc * 4);      // (activated tensor instead of mask bits: tests / tools)
                                 else m = rw * bsc + bsh;
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) dz[c] = m[c] > 0.f ? v[c] : 0.f;
                             }
                             ssum += dz;
-                            ssq += dz * ((rw - bmu) * bis);
+                            { const f32x4 xh_ = (rw - bmu) * bis; for (int c_ = 0; c_ < 4; ++c_) ssq[c_] = __builtin_fmaf(dz[c_], xh_[c_], ssq[c_]); }
                         } else {
                             ssum += v;
-                            ssq += v * v;
+                            for (int c_ = 0; c_ < 4; ++c_) ssq[c_] = __builtin_fmaf(v[c_], v[c_], ssq[c_]);      // (explicit: the same rounding in every instantiation)
                         }
                     }
                 }
@@ -1332,15 +1344,15 @@ static __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     }
 }
 
-template <int MT, int NT, bool BNBWD, int SPLIT>
+template <int MT, int NT, bool BNBWD, int SPLIT, int FL = -1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-    conv_body<MT, NT, BNBWD, SPLIT, false>(a);
+    conv_body<MT, NT, BNBWD, SPLIT, false, false, false, false, FL>(a);
 }
 
 // the in-wave pipelined form (f16x3 operands; conv_pipe.hip)
 // BITS (fused BatchNorm backward only): the ReLU mask comes as sign bits (in_mask); otherwise it is recomputed from the raw
 // conv output (in_act is not supported here: such launches stay on conv_mfma_kernel)
-template <int MT, int NT, bool BNBWD, bool BITS = false, bool PRE = false, bool M16 = false>
+template <int MT, int NT, bool BNBWD, bool BITS = false, bool PRE = false, bool M16 = false, int FL = -1>
 __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(ConvArgs a) {        // two blocks per CU: 256 registers per lane
-    conv_body<MT, NT, BNBWD, 3, true, BITS, PRE, M16>(a);
+    conv_body<MT, NT, BNBWD, 3, true, BITS, PRE, M16, FL>(a);
 }

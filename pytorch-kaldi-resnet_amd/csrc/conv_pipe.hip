@@ -23,10 +23,25 @@ static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
         ConvArgs b = a;
         b.flags = a.flags & ~SPK_CONV_M16;
         if constexpr (MT == 3 && NT == 2) {
-            if (a.flags & SPK_IN_PRESPLIT)
-                hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, true, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, b);
-            else
-                hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, false, true>), dim3(a.nblocks), dim3(256), lds_bytes, st, b);
+            // the flag combinations of the training step as compile-time variants (conv_kernel.h, FL): pair-input data gradients with the BatchNorm-backward statistics (mask recomputed from
+            // the raw tensor), with the masked shortcut add + the statistics by sign bits, with the masked add alone; anything
+            // else (eval-mode epilogues, activation tensors as masks): the generic instantiation
+            const int var = b.flags | (b.add_mask ? SPK_FL_ADDMASK : 0) | (b.bn_mask ? SPK_FL_BNMASK : 0) | (b.bn_act ? (1 << 30) : 0);
+#define LP(PREV, VV) hipLaunchKernelGGL((conv_pipe_kernel<MT, NT, false, false, PREV, true, VV>), dim3(a.nblocks), dim3(256), lds_bytes, st, b)
+#ifdef SPK_NO_FL_VARIANTS
+            if (a.flags & SPK_IN_PRESPLIT) LP(true, -1); else LP(false, -1);
+#else
+            switch (var) {
+                // (the forward form sits at its 256-register bound: its variants spill 10 registers - generic instantiation)
+                case SPK_IN_PRESPLIT | SPK_EPI_STATS | SPK_EPI_BNBWD: LP(true, SPK_IN_PRESPLIT | SPK_EPI_STATS | SPK_EPI_BNBWD); break;
+                case SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_ADDMASK | SPK_FL_BNMASK:
+                    LP(true, SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_ADDMASK | SPK_FL_BNMASK); break;
+                case SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_FL_ADDMASK: LP(true, SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_FL_ADDMASK); break;
+                default:
+                    if (a.flags & SPK_IN_PRESPLIT) LP(true, -1); else LP(false, -1);
+            }
+#endif
+#undef LP
         } else {
             spk_set_error("spk_conv_mfma: no 16x16x32 pipelined kernel for MT=%d NT=%d", MT, NT);
             return -1;

@@ -6,10 +6,44 @@
 
 template <int MT, int NT, int SPLIT>
 static int launch_split(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
-    if (a.flags & SPK_IN_BNBWD)
+    if (a.flags & SPK_IN_BNBWD) {
+#ifndef SPK_NO_FL_VARIANTS
+        // the two fused BatchNorm-backward data gradients of a 32-channel BasicBlock as compile-time variants: conv2's (mask of the
+        // block output as sign bits, pair side output, statistics of bn1's backward with the mask recomputed) and conv1's (mask
+        // recomputed, masked shortcut add, statistics of the previous block's last BatchNorm by sign bits)
+        if constexpr (SPLIT == 3 && MT == 2 && NT == 1) {
+            const int var = a.flags | (a.add_mask ? SPK_FL_ADDMASK : 0) | (a.bn_mask ? SPK_FL_BNMASK : 0) | (a.in_mask ? SPK_FL_INMASK : 0);
+            constexpr int V2 = SPK_IN_BNBWD | SPK_SIDE_PRESPLIT | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_INMASK;
+            constexpr int V1 = SPK_IN_BNBWD | SPK_SIDE_PRESPLIT | SPK_EPI_ADD | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_ADDMASK | SPK_FL_BNMASK;
+            if (!a.in_act && !a.bn_act && !a.side_dz && (var == V1 || var == V2)) {
+                if (var == V2) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true, SPLIT, V2>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+                else hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true, SPLIT, V1>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+                SPK_LAUNCH_CHECK("spk_conv_mfma(split)");
+                return 0;
+            }
+        }
+#endif
         hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true, SPLIT>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
-    else
+    } else {
+#ifndef SPK_NO_FL_VARIANTS
+        // the forward launches of the training step as compile-time flag variants (conv_kernel.h, FL), f16x3 mode
+        if constexpr (SPLIT == 3 && ((MT == 2 && NT == 1) || (MT == 1 && NT == 2) || (MT == 2 && NT == 2))) {
+            if (!a.add_mask && !a.bn_mask && !a.bn_act) {
+                if (a.flags == (SPK_IN_AFFINE_RELU | SPK_EPI_STATS)) {
+                    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false, SPLIT, SPK_IN_AFFINE_RELU | SPK_EPI_STATS>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+                    SPK_LAUNCH_CHECK("spk_conv_mfma(split)");
+                    return 0;
+                }
+                if (a.flags == SPK_EPI_STATS) {
+                    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false, SPLIT, SPK_EPI_STATS>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+                    SPK_LAUNCH_CHECK("spk_conv_mfma(split)");
+                    return 0;
+                }
+            }
+        }
+#endif
         hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false, SPLIT>), dim3(a.nblocks), dim3(256), lds_bytes, st, a);
+    }
     SPK_LAUNCH_CHECK("spk_conv_mfma(split)");
     return 0;
 }

@@ -104,8 +104,11 @@ def test_forward_parity(P, gold_dir, name):
     loss = torch.nn.functional.cross_entropy(logits, yg)
     # train-mode BN over a batch of 2-4 utterances amplifies rounding differences more than eval mode
     assert srel(logits.detach().cpu().numpy(), g["logits_train"]) < 2e-4
-    # 1e-4 at step 0; ResNet-101 at batch 2 (train-mode BatchNorm over two utterances): 1.1e-4 measured
-    assert abs(float(loss) - float(g["loss_train"])) < (2e-4 if name == "r101_aam" else 1e-4), name
+    # 1e-4 at step 0.  ResNet-101 at batch 2 (33 Bottleneck blocks, train-mode BatchNorm over two utterances):
+    # the reference itself moves this loss by 1.0-1.3e-4 when every input value is perturbed by <= 1 ulp and by 1.14e-4 between fp32
+    # and fp64 (oracle run, round 4); budget = 3 x that self-distance, as for the loss curves.  Measured here:
+    # 1.1e-4 ... 2.7e-4 depending on the operand mode and the summation order of the statistics
+    assert abs(float(loss) - float(g["loss_train"])) < (4e-4 if name == "r101_aam" else 1e-4), name
     # BN running statistics after exactly one training forward
     sd = m.state_dict()
     for key in g.files:
@@ -218,7 +221,7 @@ def test_backward_parity(P, gold_dir, name):
     for i, n in enumerate(names):
         ref = float(g["grad_norm"][i])
         assert abs(float(hip[n].norm()) - ref) <= tol * ref + 1e-5, n
-    assert abs(loss_hip - float(g["loss_train"])) < (2e-4 if name == "r101_aam" else 1e-4), name
+    assert abs(loss_hip - float(g["loss_train"])) < (4e-4 if name == "r101_aam" else 1e-4), name      # (budget: see test_forward_parity)
 
 
 def test_fused_step_equals_autograd_path(P, gold_dir):
