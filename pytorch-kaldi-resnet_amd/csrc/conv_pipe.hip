@@ -32,7 +32,12 @@ static int launch_pipe(const ConvArgs& a, size_t lds_bytes, hipStream_t st) {
             if (a.flags & SPK_IN_PRESPLIT) LP(true, -1); else LP(false, -1);
 #else
             switch (var) {
-                // (the forward form sits at its 256-register bound: its variants spill 10 registers - generic instantiation)
+                // (the forward form sits at its 256-register bound: its variants spill 10 registers - generic instantiation unless
+                //  SPK_FL_FWD_PIPE is defined: A/B builds)
+#ifdef SPK_FL_FWD_PIPE
+                case SPK_IN_AFFINE_RELU | SPK_EPI_STATS: LP(false, SPK_IN_AFFINE_RELU | SPK_EPI_STATS); break;
+                case SPK_EPI_STATS: LP(false, SPK_EPI_STATS); break;
+#endif
                 case SPK_IN_PRESPLIT | SPK_EPI_STATS | SPK_EPI_BNBWD: LP(true, SPK_IN_PRESPLIT | SPK_EPI_STATS | SPK_EPI_BNBWD); break;
                 case SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_ADDMASK | SPK_FL_BNMASK:
                     LP(true, SPK_IN_PRESPLIT | SPK_EPI_ADD | SPK_EPI_STATS | SPK_EPI_BNBWD | SPK_FL_ADDMASK | SPK_FL_BNMASK); break;

@@ -24,6 +24,9 @@ static __device__ __forceinline__ s16x8 tr_read8m(const unsigned char* p0, const
 #define WM_NX 7      // X halo float4 per thread: halo_pix <= 16 * WM_NX pixels of 64 channels
 #define WM_ND 4      // dY float4 per thread: npix <= 16 * WM_ND
 
+// VAR: compile-time variant of the two run-time switches of the staging pass (so that its per-item branches fold away): bit 0 = fused
+// input BatchNorm + ReLU on X, bit 1 = dY is an f16 pair tensor; VAR < 0: both read from the argument block.
+template <int VAR>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int NTAPS = 9, KS = 3, WN = 2;
@@ -55,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
     const int npix_pad = nsteps_all << 4;
     unsigned char* xs = ldsb;
     unsigned char* dys = ldsb + halo_pix * PX;
-    const int flags = a.flags;
+    const int flags = VAR >= 0 ? ((VAR & 1) ? SPK_IN_AFFINE_RELU : 0) : a.flags;
     const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
     const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
-    const bool dy_pairs = (flags & SPK_DY_PRESPLIT) != 0;      // dY is an f16 pair tensor: staged by plain copy
+    const bool dy_pairs = VAR >= 0 ? (VAR & 2) != 0 : (a.flags & SPK_DY_PRESPLIT) != 0;      // dY is an f16 pair tensor: staged by plain copy
 
     f32x16 acc[NTAPS];
 #pragma unroll
@@ -219,7 +222,14 @@ int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st) {
     const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 384 + (size_t)npix_pad * (2 * 192 + 64);
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
-    hipLaunchKernelGGL(conv_wgrad_wm_kernel, grid, dim3(256), lds_bytes, st, a);
+    const int var = ((a.flags & SPK_IN_AFFINE_RELU) ? 1 : 0) | ((a.flags & SPK_DY_PRESPLIT) ? 2 : 0);
+#ifdef SPK_NO_FL_VARIANTS
+    hipLaunchKernelGGL(conv_wgrad_wm_kernel<-1>, grid, dim3(256), lds_bytes, st, a);
+#else
+    if (var == 3) hipLaunchKernelGGL(conv_wgrad_wm_kernel<3>, grid, dim3(256), lds_bytes, st, a);
+    else if (var == 2) hipLaunchKernelGGL(conv_wgrad_wm_kernel<2>, grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_wm_kernel<-1>, grid, dim3(256), lds_bytes, st, a);
+#endif
     SPK_LAUNCH_CHECK("spk_conv_wgrad(2x2 waves)");
     return 0;
 }
