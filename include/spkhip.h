@@ -130,6 +130,15 @@ int spk_conv_mfma(const float* in, const float* wpk, float* out, const float* in
  * the kernel's register prefetch window: halo pixels <= *max_halo_pix, TH*TW <= *max_tile_pix (spk_conv_wgrad_limits). */
 int spk_conv_wgrad_limits(int WN, int* max_halo_pix /*host*/, int* max_tile_pix /*host*/);
 size_t spk_conv_wgrad_workspace(int nsplit, int ksize, int Cin, int Cout);
+/* Streaming 3x3 forward convolution of the 32-channel layer: 32 -> 32 channels, stride 1, padding 1, f16x3 operands - conv1 / conv2 of
+ * the BasicBlocks of layer 1 (scripts/model.py:12-15,48-64).  Persistent blocks over 8 x 16-pixel tiles, the weights as matrix-core
+ * fragments in LDS for the life of a block, the 10 x 18 halo staged once per tile from whole 128-byte lines one tile ahead (fused
+ * BatchNorm + ReLU with SPK_IN_AFFINE_RELU), stores from the accumulator layout.  in / out: [B][H][W][32]; wpk:
+ * spk_pack_conv_weight_split(split = 3, transpose = 0) of the [32][32][3][3] weights; flags: SPK_EPI_STATS [| SPK_IN_AFFINE_RELU];
+ * stats: [4 * nblocks][32][2] partial rows (sum, sum of squares) for spk_bn_finalize; in_amax REQUIRED, out_amax optional;
+ * nblocks: persistent blocks (<= tiles; two per CU).  Same products as spk_conv_mfma; another order of the statistics partials. */
+int spk_conv3x3_c32_stream(const float* in, const float* wpk, float* out, const float* in_scale, const float* in_shift, float* stats,
+                           int B, int H, int W, int flags, const unsigned* in_amax, unsigned* out_amax, int nblocks, void* stream);
 /* Streaming 1x1 convolution, C -> C channels (C = 32, 64 or 128), stride 1, f16x3 operands: forward and data gradient of the 1x1
  * convolutions of the Bottleneck blocks (scripts/model.py:104-110,118-126) - a GEMM [P pixels][C] x [C][C] by persistent blocks that
  * keep the whole weight matrix in registers, stage every pixel once (whole 128-byte lines; fused BatchNorm + ReLU with

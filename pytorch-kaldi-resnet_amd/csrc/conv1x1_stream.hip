@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Conv1x1Args a) {
     const bool has_addmask = VAR >= 0 ? (VAR & V_ADDMASK) != 0 : a.add_mask != nullptr;
     const bool has_bnmask = VAR >= 0 ? (VAR & V_BNMASK) != 0 : a.bn_mask != nullptr;
     const float sig = spk_sigma_from_amax_bits(*a.in_amax);
-    const float inv = (1.f / sig) * (1.f / spk_sigma_from_amax_bits(*a.w_amax));     // (two exact powers of two)
+    const float inv_sig = 1.f / sig, inv_wsig = 1.f / spk_sigma_from_amax_bits(*a.w_amax);      // (two factors: their product may leave the fp32 range)
     const bool pairs = (flags & SPK_IN_PRESPLIT) != 0, aff = (flags & SPK_IN_AFFINE_RELU) != 0;
 
     // the weights of this wave's 32 output channels: B fragments [group][term], 16 bytes per lane each
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Conv1x1Args a) {
                 const int e = e0 + k;
                 const int p = pw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (ragged && p >= Pn) continue;
-                float val = acc[i][e] * inv;
+                float val = acc[i][e] * inv_sig * inv_wsig;
                 if (flags & SPK_EPI_ADD) {
                     float ad = adv[k];
                     if (has_addmask) ad = ((amw[k] >> r) & 1u) ? ad : 0.f;

@@ -29,6 +29,7 @@ _SIGS = {
     "spk_build_flags": [],
     "spk_pack_conv_weights_batched": [_P, _I, _I, _I, _P],
     "spk_conv_mfma": [_P] * 21 + [_I] * 14 + [_IP, _IP, _IP] + [_I] * 8 + [_P, _P, _P, _P],
+    "spk_conv3x3_c32_stream": [_P] * 6 + [_I] * 4 + [_P, _P, _I, _P],
     "spk_conv1x1_stream": [_P] * 11 + [_L, _I, _I, _P, _P, _I, _P],
     "spk_conv1x1_stream_rows": [_I, _I],
     "spk_conv_wgrad": [_P] * 6 + [_I] * 16 + [_P, _P, _P],

@@ -289,11 +289,35 @@ def _conv1x1_stream(x, wpk, out, in_affine, epi_add, add_mask, bn_bwd, want_stat
     return stats
 
 
+STREAM_C32 = os.environ.get("SPK_STREAM_C32", "1") == "1"
+STREAM_C32_BLOCKS = int(os.environ.get("SPK_STREAM_C32_BLOCKS", "512"))
+
+
+def _conv3x3_c32_stream(x, wpk, out, in_affine, in_amax, out_amax):
+    B, H, W, _ = x.shape
+    ntiles = B * (-(-H // 8)) * (-(-W // 16))
+    nblocks = max(1, min(STREAM_C32_BLOCKS, ntiles))
+    stats = torch.empty(4 * nblocks, 32, 2, device=x.device, dtype=torch.float32)
+    flags = EPI_STATS | (IN_AFFINE_RELU if in_affine is not None else 0)
+    call("spk_conv3x3_c32_stream", ptr(x), ptr(wpk), ptr(out), ptr(in_affine[0]) if in_affine else None,
+         ptr(in_affine[1]) if in_affine else None, ptr(stats), B, H, W, flags, ptr(in_amax), ptr(out_amax), nblocks, stream(),
+         label="conv3x3_c32_stream_kernel" + (" C32 %dx%d" % (H, W) if LABEL_SHAPES else ""),
+         flops=2.0 * B * H * W * 32 * 32 * 9, nbytes=4.0 * (2 * B * H * W * 32 + wpk.numel()))
+    return stats
+
+
 def _conv_launch(x, wpk, out, Cout, taps, IS, OS, ooy, oox, OH, OW, in_affine, epi_affine, epi_add, relu, want_stats,
                  bn_bwd=None, in_bnbwd=None, side=None, split=0, add_mask=None, in_amax=None, out_amax=None, side_amax=None,
                  in_presplit=False, side_presplit=False):
     B, IH, IW, Cin = x.shape
     OHf, OWf = out.shape[1], out.shape[2]
+    # Streaming 3x3 forward kernel of the 32-channel layer (csrc/conv3x3_c32_stream.hip): 32 -> 32 channels, stride 1, the forward tap
+    # order, raw output + statistics, plain or fused-BatchNorm input.  (A data gradient has mirrored taps: general kernel.)
+    if (STREAM_C32 and split == 3 and Cin == 32 and Cout == 32 and IS == 1 and OS == 1 and ooy == 0 and oox == 0
+            and (IH, IW) == (OH, OW) == (OHf, OWf) and want_stats and in_bnbwd is None and side is None and epi_affine is None
+            and epi_add is None and not relu and bn_bwd is None and not in_presplit and not side_presplit and add_mask is None
+            and list(taps) == [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)] and B * OH * OW * 32 < 2 ** 31 - 65536):
+        return _conv3x3_c32_stream(x, wpk, out, in_affine, in_amax, out_amax)
     # Streaming 1x1 kernel (csrc/conv1x1_stream.hip): C -> C channels at stride 1 in the f16x3 mode, training-mode epilogues only
     # (raw output + statistics; data gradients: shortcut add with or without its sign mask, BatchNorm-backward statistics with the
     # mask as sign bits or recomputed from the raw tensor).  Everything else - eval-mode epilogues, strided 1x1, other widths,

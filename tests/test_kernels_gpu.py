@@ -945,3 +945,41 @@ def test_streaming_1x1_kernel_equals_the_general_kernel(ops, C, B, H, Wd):
     # and against the definition (torch CPU fp32)
     refc = F.conv2d(x, w)
     assert relerr(nchw(run(True, 512)["fwd"]), refc) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,Wd", [(3, 80, 300), (2, 13, 45), (2, 5, 9), (1, 8, 16), (4, 80, 203)])
+def test_streaming_3x3_forward_of_the_32_channel_layer_equals_the_general_kernel(ops, B, H, Wd):
+    """conv3x3_c32_stream_kernel (persistent blocks, weights in LDS, halo staged one tile ahead from whole lines, stores from the
+    accumulator layout) against conv_mfma_kernel on the forward convolutions of layer 1 (reference scripts/model.py:48-64), plain
+    input and fused BatchNorm + ReLU input: ragged right / bottom edges, images smaller than a tile, grids of 1 / 5 / 512 blocks.
+    Same operand terms, the same three products per tap and channel group in the same order: outputs bit-identical; the
+    statistics partials sum to the same totals (1e-5); and the definition (torch CPU fp32) within the usual 2e-5."""
+    if ops.SPLIT != 3:
+        pytest.skip("the streaming kernel exists for the f16x3 operand mode")
+    x = rnd(51, B, 32, H, Wd, scale=1.5, shift=0.2)
+    w = rnd(52, 32, 32, 3, 3, scale=0.2)
+    xg = nhwc(x)
+    wpk = ops.pack_conv_weight(w.cuda())
+    isc, ish = rnd(53, 32, scale=0.5, shift=1.0).cuda(), rnd(54, 32, scale=0.3).cuda()
+
+    def run(stream, blocks):
+        old = ops.STREAM_C32, ops.STREAM_C32_BLOCKS
+        ops.STREAM_C32, ops.STREAM_C32_BLOCKS = stream, blocks
+        try:
+            amx = torch.zeros(1, device="cuda", dtype=torch.int32)
+            o0, s0 = ops.conv_fwd(xg, wpk, 32, 3, 1, stats=True, out_amax=amx)
+            o1, s1 = ops.conv_fwd(xg, wpk, 32, 3, 1, in_affine=(isc, ish), stats=True)
+            torch.cuda.synchronize()
+            return o0, s0, o1, s1, amx.view(torch.float32).clone()
+        finally:
+            ops.STREAM_C32, ops.STREAM_C32_BLOCKS = old
+
+    ref = run(False, 512)
+    for blocks in (1, 5, 512):
+        got = run(True, blocks)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), blocks
+        assert float(got[4]) == float(ref[4])
+        for i in (1, 3):
+            a, b = got[i].double().sum(0), ref[i].double().sum(0)
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (i, blocks)
+    assert relerr(nchw(run(True, 512)[0]), F.conv2d(x, w, None, 1, 1)) < 2e-5
