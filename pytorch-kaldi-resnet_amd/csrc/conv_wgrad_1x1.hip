@@ -22,7 +22,9 @@ static __device__ __forceinline__ s16x8 tr_read8g(const unsigned char* p0, const
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int WK, int WN, int CG>
+// VAR >= 0: compile-time variant of the staging switches (bit 0 fused input BatchNorm + ReLU on X, bit 1 dY is an f16 pair tensor);
+// VAR < 0: read from the argument block
+template <int WK, int WN, int CG, int VAR = -1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_1x1_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int PX = CG * 192;                          // X bytes per staged pixel: [CG][3-term pitch][32 ch fp16]
@@ -59,10 +61,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_1x1_kernel(WgradArgs a) {
     const int npix_pad = nsteps_all << 4;
     unsigned char* xs = ldsb;
     unsigned char* dys = ldsb + npix_pad * PX;
-    const int flags = a.flags;
+    const int flags = VAR >= 0 ? ((VAR & 1) ? SPK_IN_AFFINE_RELU : 0) : a.flags;
     const float sig_x = a.x_amax ? spk_sigma_from_amax_bits(*a.x_amax) : SPK_F16_ACT_SIGMA;
     const float sig_d = a.dy_amax ? spk_sigma_from_amax_bits(*a.dy_amax) : 1.f;
-    const bool dy_pairs = (a.flags & SPK_DY_PRESPLIT) != 0;    // dY is an f16 pair tensor: staged by plain copy
+    const bool dy_pairs = VAR >= 0 ? (VAR & 2) != 0 : (a.flags & SPK_DY_PRESPLIT) != 0;    // dY is an f16 pair tensor: staged by plain copy
 
     f32x16 acc[CG];
 #pragma unroll
@@ -241,7 +243,10 @@ static int launch_g(const WgradArgs& a, hipStream_t st) {
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(1x1): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / (32 * CG)) * (a.Cout / (32 * WN)));
-    hipLaunchKernelGGL((conv_wgrad_1x1_kernel<WK, WN, CG>), grid, dim3(256), lds_bytes, st, a);
+    const int var = ((a.flags & SPK_IN_AFFINE_RELU) ? 1 : 0) | ((a.flags & SPK_DY_PRESPLIT) ? 2 : 0);
+    if (var == 3) hipLaunchKernelGGL((conv_wgrad_1x1_kernel<WK, WN, CG, 3>), grid, dim3(256), lds_bytes, st, a);
+    else if (var == 2) hipLaunchKernelGGL((conv_wgrad_1x1_kernel<WK, WN, CG, 2>), grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_1x1_kernel<WK, WN, CG>), grid, dim3(256), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_wgrad(1x1)");
     return 0;
 }

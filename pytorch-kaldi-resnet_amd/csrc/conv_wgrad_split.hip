@@ -54,7 +54,9 @@ static __device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
 }
 
 // NTAPS = 9: 3x3 (pad 1); NTAPS = 1: 1x1 (pad 0; the f16x3 mode also runs the Bottleneck / downsample 1x1 convolutions here)
-template <int NTAPS, int WK, int WN, int SPLIT, int NX>
+// VAR >= 0: compile-time variant of the staging switches (bit 0 fused input BatchNorm + ReLU on X, bit 1 dY is an f16 pair tensor): the
+// per-item branches of the staging pass fold away; VAR < 0: read from the argument block
+template <int NTAPS, int WK, int WN, int SPLIT, int NX, int VAR = -1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int KS = NTAPS == 9 ? 3 : 1;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradArgs a) {
     const int npix_pad = nsteps_all << 4;
     unsigned char* xs = ldsb;
     unsigned char* dys = ldsb + halo_pix * PX;
-    const int flags = a.flags;
+    const int flags = VAR >= 0 ? (((VAR & 1) ? SPK_IN_AFFINE_RELU : 0) | ((VAR & 2) ? SPK_DY_PRESPLIT : 0)) : a.flags;
     constexpr int NTERM = SPLIT == 3 ? 2 : 3;
     float sig_x = 1.f, sig_d = 1.f;
     if constexpr (SPLIT == 3) {
@@ -585,6 +587,20 @@ static int launch_one(const WgradArgs& a, int split, hipStream_t st) {
     dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / (32 * WN)));       // see wgrad_block
     const bool small = a.halo_h * a.halo_w <= 32 * 4;
     if (split == 3) {
+        const int var = ((a.flags & SPK_IN_AFFINE_RELU) ? 1 : 0) | ((a.flags & SPK_DY_PRESPLIT) ? 2 : 0);
+        // the layer-1 weight gradients of the training step (3x3, 32 channels: WK 4, WN 1, the large prefetch window) with pair dY
+        if constexpr (NTAPS == 9 && WK == 4 && WN == 1) {
+            if (!small && var == 3) {
+                hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, WGRAD_NX, 3>), grid, dim3(256), lds_bytes, st, a);
+                SPK_LAUNCH_CHECK("spk_conv_wgrad(split)");
+                return 0;
+            }
+            if (!small && var == 2) {
+                hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, WGRAD_NX, 2>), grid, dim3(256), lds_bytes, st, a);
+                SPK_LAUNCH_CHECK("spk_conv_wgrad(split)");
+                return 0;
+            }
+        }
         if (small) hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, 4>), grid, dim3(256), lds_bytes, st, a);
         else hipLaunchKernelGGL((conv_wgrad_split_kernel<NTAPS, WK, WN, 3, WGRAD_NX>), grid, dim3(256), lds_bytes, st, a);
     } else if constexpr (NTAPS == 9) {
