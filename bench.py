@@ -302,7 +302,18 @@ def roofline_object(recs, npass):
         bmod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bmod)
         pj = json.load(open(pmc))
-        ent = pj["kernels"].get(name.replace(",", ", "))
+        # the profiler's kernel names carry template arguments the label does not (the compile-time flag variants of round 4:
+        # "conv_pipe_kernel<3, 2, false, false, true, true, 16432>"): every instance of the labelled kernel, weighted by launches
+        key = name.split(" C")[0].replace(",", ", ")
+        ents = [v for k, v in pj["kernels"].items() if k == key or (key.endswith(">") and k.startswith(key[:-1] + ","))
+                or (not key.endswith(">") and k.startswith(key + "<"))]
+        if not ents and key.startswith("spk_"):  # C-ABI entry point labels: spk_bn_bwd_apply launches bn_bwd_apply_kernel
+            kk = key[4:] + "_kernel"
+            ents = [v for k, v in pj["kernels"].items() if k == kk or k.startswith(kk + "<")]
+        ent = None
+        if ents:
+            nl = sum(e["launches"] for e in ents)
+            ent = {"hbm_bytes_per_launch": sum(e["hbm_bytes_per_launch"] * e["launches"] for e in ents) / max(nl, 1)}
         if pj.get("csrc_fingerprint") != bmod.csrc_fingerprint():
             traffic_note = "committed PMC pass is stale (csrc changed since %s): refused" % pj.get("csrc_fingerprint")
         elif ent:

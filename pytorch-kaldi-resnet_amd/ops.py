@@ -737,8 +737,15 @@ def bn_apply(raw, scale, shift, res=None, res_affine=None, relu=True, out=None, 
     mk = torch.empty(N * (C // 32), device=raw.device, dtype=torch.int32) if mask else None
     call("spk_bn_apply", ptr(raw), ptr(scale), ptr(shift), ptr(res),
          ptr(res_affine[0]) if res_affine else None, ptr(res_affine[1]) if res_affine else None, ptr(out), ptr(mk), N, C,
-         1 if relu else 0, ptr(amax_out), stream())
+         1 if relu else 0, ptr(amax_out), stream(),
+         nbytes=4.0 * raw.numel() * (2 + (1 if res is not None else 0)) + (raw.numel() / 8 if mask else 0))
     return (out, mk) if mask else out
+
+
+def _bn_bwd_bytes(raw, mask_mode, passes):
+    """algorithmic bytes of a BatchNorm-backward stream kernel: `passes` fp32 tensors (dy, raw, draw / dz) + the mask source"""
+    n = raw.numel()
+    return 4.0 * n * passes + {MASK_NONE: 0.0, MASK_RAW: 0.0, MASK_ACT: 4.0 * n}.get(mask_mode, n / 8.0)
 
 
 def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=None, dz_out=None, accumulate=False,
@@ -758,7 +765,7 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
         nblk = hip.lib().spk_bn_stats_blocks(N, C)
         part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
         call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
-             N, C, mask_mode, ptr(chan_amax), stream())
+             N, C, mask_mode, ptr(chan_amax), stream(), nbytes=_bn_bwd_bytes(raw, mask_mode, 2))
     else:
         assert chan_amax is None, "chan_amax comes out of the reduction pass: partial must be None"
         part, nblk = partial, partial.shape[0]
@@ -768,7 +775,8 @@ def bn_backward(dy, raw, act, bn4, gamma, dgamma, dbeta, mask_mode, draw_out=Non
     if draw_out is None:
         draw_out = torch.empty_like(raw)
     call("spk_bn_bwd_apply", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(coef),
-         ptr(draw_out), ptr(dz_out), N, C, mask_mode, ptr(amax_out), ptr(pair[2]) if pair else None, stream())
+         ptr(draw_out), ptr(dz_out), N, C, mask_mode, ptr(amax_out), ptr(pair[2]) if pair else None, stream(),
+         nbytes=_bn_bwd_bytes(raw, mask_mode, 3 + (1 if dz_out is not None else 0)))
     return draw_out
 
 
@@ -795,7 +803,7 @@ def bn_bwd_partial(dy, raw, act, bn4, mask_mode, chan_amax=None):
     nblk = hip.lib().spk_bn_stats_blocks(N, C)
     part = torch.empty(nblk, C, 2, device=raw.device, dtype=torch.float32)
     call("spk_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(act), ptr(bn4[0]), ptr(bn4[1]), ptr(bn4[2]), ptr(bn4[3]), ptr(part),
-         N, C, mask_mode, ptr(chan_amax), stream())
+         N, C, mask_mode, ptr(chan_amax), stream(), nbytes=_bn_bwd_bytes(raw, mask_mode, 2))
     return part
 
 
