@@ -590,6 +590,13 @@ def main():
                     bad.append((cv.cin, cv.cout, cv.k, transpose))
         torch.cuda.synchronize()
         repack_ok = not bad
+        if bad and not all(bool(torch.isfinite(p_).all()) for p_ in model.parameters()):
+            # NaN != NaN: not a stale pack.  The timed steps train on ONE fixed batch; once it is memorised (loss ~0.03, ~250 steps
+            # at lr 0.1) a target cosine reaches 1.0 and the gradient of sqrt(1 - cos^2) (scripts/model.py:487) is infinite - in
+            # the reference's own formula, in the native-fp32 operand mode as in f16x3 (tools/long_run.py, profiles/r04_long_run.log)
+            raise SystemExit("bench: the weights are no longer finite after %d steps on one fixed batch (AAM's sqrt(1 - cos^2) has an "
+                             "unbounded gradient at cos = 1, reached once the batch is memorised): use fewer than ~200 steps"
+                             % (args.warmup + args.steps))
         if bad:
             raise SystemExit("bench: the replayed hipGraph uses stale packed conv weights %s - not a valid training step" % bad)
     log("timed region done: %.3f s for %d steps (host enqueue %.1f ms/step)" % (dt, args.steps, t_host / args.steps * 1e3))

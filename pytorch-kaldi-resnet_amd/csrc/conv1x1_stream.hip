@@ -22,6 +22,13 @@
 // summation order of the statistics partials (they end in the same fp64 finalize).
 #include "spk_common.h"
 
+#ifndef C11_KD
+#define C11_KD 0    // K-loop steps (2 reads + 3 matrix instructions each) whose A fragments are requested ahead of their use; 0 = each
+                    // step's reads directly in front of its products (what the compiler schedules by itself).  3 measured +-0 inside the
+                    // ResNet-101 step (128 channels 0.107 vs 0.106 ms, 64 channels 0.209 vs 0.212): the other waves of the SIMD fill the
+                    // LDS latency here; the 3x3 kernel (conv3x3_c32_stream.hip, 18 steps per tile) gains 4 % from the same change
+#endif
+
 struct Conv1x1Args {
     const float* in;           // [P][Cin] fp32, or f16 pair tensor (SPK_IN_PRESPLIT)
     const float* wpk;          // f16x3 packed weights behind their 16-byte header
@@ -149,19 +156,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(Conv1x1Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         const unsigned char* rd = lds1 + (wm * 64 + r) * PITCH + h * 16;
+        // software-pipelined by hand: the A fragments of step s + C11_KD are requested before the matrix instructions of step s
+        // (step = (group g, row tile i), g-major: the accumulation order of a row tile is unchanged); left to the compiler every
+        // step's two reads sit directly in front of its products - 2 KG exposed LDS latencies per tile
+        constexpr int NS = 2 * KG;
+        f32x4 fr[C11_KD + 1][2];
+        auto frag = [&](int s2, f32x4* f) {
+            const int g = s2 >> 1, i = s2 & 1;
+            f[0] = *(const f32x4*)(rd + i * (32 * PITCH) + g * 64);
+            f[1] = *(const f32x4*)(rd + i * (32 * PITCH) + g * 64 + 32);
+        };
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            f32x4 af[2][2];
+        for (int s2 = 0; s2 < C11_KD; ++s2) frag(s2, fr[s2]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) af[i][s] = *(const f32x4*)(rd + i * (32 * PITCH) + g * 64 + s * 32);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bw[g][1]), acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][1]), __builtin_bit_cast(f16x8, bw[g][0]), acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bw[g][0]), acc[i], 0, 0, 0);
-            }
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (s2 + C11_KD < NS) frag(s2 + C11_KD, fr[(s2 + C11_KD) % (C11_KD + 1)]);
+            __builtin_amdgcn_sched_barrier(0);           // (the scheduler would sink these reads back in front of their use)
+            const f32x4* f = fr[s2 % (C11_KD + 1)];
+            const int g = s2 >> 1, i = s2 & 1;
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[0]), __builtin_bit_cast(f16x8, bw[g][1]), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[1]), __builtin_bit_cast(f16x8, bw[g][0]), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[0]), __builtin_bit_cast(f16x8, bw[g][0]), acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // epilogue from the accumulator layout: register e of row tile i = pixel (e & 3) + 8 (e >> 2) + 4 h of the tile, channel r

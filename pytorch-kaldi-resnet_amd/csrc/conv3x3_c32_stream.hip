@@ -38,8 +38,20 @@ struct Conv3x3C32Args {
 #define C32_PIX 144                  // LDS bytes per halo pixel: [2 groups][2 terms][16 ch fp16] + 16
 #define C32_ROW 2816                 // LDS bytes per halo row: 18 x 144 = 2592, padded to 11 x 256 (conflict-free fragment reads)
 #define C32_WBYTES (9 * 2 * 2 * 1024)
+#ifndef C32_KD
+#define C32_KD 2                     // K-loop steps whose fragment reads are in flight ahead of the matrix instructions
+#endif
 #ifndef C32_DEPTH
 #define C32_DEPTH 2                  // tiles in flight (register sets of six 16-byte loads): 1 measured 0.498 ms per launch, 2 0.438
+#endif
+
+#ifdef C32_STAMPS
+// diagnostic build (tools/variant.sh c32stamps conv3x3_c32_stream.hip -DC32_STAMPS): per-block sums of the shader-clock time wave 0
+// spends in each phase of a tile; read back by spk_debug_stamps_c32 (tools/c32_stamps.py)
+static __device__ unsigned long long g_c32_stamps[1024][8];
+#define C32_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - last; last = now_; } while (0)
+#else
+#define C32_T(i) do { } while (0)
 #endif
 
 // VAR: 1 = fused input BatchNorm + ReLU, 0 = plain input (compile-time: the staging loop has no branch on it)
@@ -122,12 +134,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
     const unsigned char* wb = wl + lane * 16;
 
     const int G = (int)gridDim.x;
+#ifdef C32_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memtime();
+    const unsigned long long born = last;
+#endif
     auto step = [&](int tile, f32x4* v, unsigned& okm) {
         int b, y0, x0;
         tile_origin(tile, b, y0, x0);
+        C32_T(0);
         __syncthreads();                                 // every wave has read the previous tile (and, first time, the weights are written)
+        C32_T(1);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
+#ifdef C32_ABL_NOSTAGE
+            break;
+#endif
             if (u == 5 && !item5) break;
             f32x4 w = v[u];
             if constexpr (AFF) {
@@ -143,30 +164,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
             *(uint2*)(hl + loff[u]) = t0;
             *(uint2*)(hl + loff[u] + 32) = t1;
         }
+        C32_T(2);
         __syncthreads();
+        C32_T(3);
+#ifndef C32_ABL_NOLOAD   // (C32_ABL_*: timing-only diagnostic builds with wrong results - tools/gpu/c32_abl.sh)
         if (tile + C32_DEPTH * G < a.ntiles) issue(tile + C32_DEPTH * G, v, okm);  // in flight through the next tiles' K loops and epilogues
+#endif
+        C32_T(4);
 
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         // (group-major like the general kernel, which walks the two 16-channel planes one after the other: the same accumulation
         //  order, bit-identical outputs)
+#ifdef C32_ABL_HALFK
+        constexpr int NG = 1;
+#else
+        constexpr int NG = 2;
+#endif
+        // software-pipelined by hand: the fragments of step s + C32_KD are requested before the matrix instructions of step s (the
+        // compiler left every step's four reads directly in front of its products: 18 exposed LDS latencies per tile)
+        constexpr int NS = NG * 9;
+        f32x4 fr[C32_KD + 1][4];
+        auto frag = [&](int s2, f32x4* f) {
+            const int g = s2 / 9, t = s2 % 9;
+            const int toff = (t / 3) * C32_ROW + (t % 3) * C32_PIX;
+            f[0] = *(const f32x4*)(rd + toff + g * 64);
+            f[1] = *(const f32x4*)(rd + toff + g * 64 + 32);
+            f[2] = *(const f32x4*)(wb + ((t * 2 + g) * 2 + 0) * 1024);
+            f[3] = *(const f32x4*)(wb + ((t * 2 + g) * 2 + 1) * 1024);
+        };
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int s2 = 0; s2 < C32_KD; ++s2) frag(s2, fr[s2]);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = (t / 3) * C32_ROW + (t % 3) * C32_PIX;
-                f32x4 af[2], bf[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    af[s] = *(const f32x4*)(rd + toff + g * 64 + s * 32);
-                    bf[s] = *(const f32x4*)(wb + ((t * 2 + g) * 2 + s) * 1024);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[1]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1]), __builtin_bit_cast(f16x8, bf[0]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), acc, 0, 0, 0);
-            }
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (s2 + C32_KD < NS) frag(s2 + C32_KD, fr[(s2 + C32_KD) % (C32_KD + 1)]);
+            __builtin_amdgcn_sched_barrier(0);           // (the scheduler would sink these reads back in front of their use)
+            const f32x4* f = fr[s2 % (C32_KD + 1)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[0]), __builtin_bit_cast(f16x8, f[3]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[1]), __builtin_bit_cast(f16x8, f[2]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[0]), __builtin_bit_cast(f16x8, f[2]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
+        C32_T(5);
         // epilogue: register e = pixel m = (e & 3) + 8 (e >> 2) + 4 h of the row tile -> tile row 2 wave + (m >> 4), column m & 15; channel r
         const bool ragged = y0 + C32_TH > H || x0 + C32_TW > W;
         float ts = 0.f, tq = 0.f;
@@ -176,13 +217,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
             const int row = e >> 3, lx = (e & 3) + 8 * ((e >> 2) & 1) + 4 * h;
             if (ragged && (y0 + 2 * wave + row >= H || x0 + lx >= W)) continue;
             const float val = acc[e] * inv_sig * inv_wsig;
+#ifndef C32_ABL_NOSTORE
             __builtin_nontemporal_store(val, ob + (row * W + lx) * 32);
+#endif
             out_mx = fmaxf(out_mx, fabsf(val));
             ts += val;
             tq = __builtin_fmaf(val, val, tq);
         }
         s_sum += (double)ts;
         s_sq += (double)tq;
+        C32_T(6);
     };
     int tile = blockIdx.x;
     if (tile < a.ntiles) issue(tile, va, okma);
@@ -194,6 +238,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
         if (C32_DEPTH > 2 && tile + 2 * G < a.ntiles) step(tile + 2 * G, vc, okmc);
     }
 
+#ifdef C32_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) {
+        for (int i = 0; i < 7; ++i) g_c32_stamps[blockIdx.x][i] = ph[i];
+        g_c32_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memtime() - born;
+    }
+#endif
     if (a.out_amax) spk_wave_amax_commit(out_mx, a.out_amax);
     if (a.flags & SPK_EPI_STATS) {
         s_sum += __shfl_xor(s_sum, 32, 64);              // lanes l and l + 32 hold the same channel
@@ -227,3 +277,13 @@ extern "C" int spk_conv3x3_c32_stream(const float* in, const float* wpk, float* 
     SPK_LAUNCH_CHECK("spk_conv3x3_c32_stream");
     return 0;
 }
+
+#ifdef C32_STAMPS
+extern "C" int spk_debug_stamps_c32(unsigned long long* out, int nblocks) {
+    if (nblocks < 0) {
+        static unsigned long long zeros[1024][8];
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_c32_stamps), zeros, sizeof(zeros));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c32_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks);
+}
+#endif
