@@ -28,15 +28,17 @@ names = ["tile origin + arrive", "barrier 1 (others still read the tile)", "conv
          "issue loads of tile + 2G", "K loop (LDS reads + MFMA)", "epilogue (stores, statistics)"]
 for label, a in (("fused BN + ReLU input", aff), ("plain input", None)):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    slot = ops._amax_fwd_fallback(x, a)              # once: without it every call below would add an absmax pass over x
+    buf_out = torch.empty(B, H, W, 32, device="cuda")
     for i in range(3):
-        out, st = ops.conv_fwd(x, wpk, 32, 3, 1, in_affine=a, stats=True)
+        out, st = ops.conv_fwd(x, wpk, 32, 3, 1, in_affine=a, stats=True, in_amax=slot, out=buf_out)
     torch.cuda.synchronize()
     assert reader is None or reader(None, -1) == 0
     NL = 20                                          # replayed from a captured graph: no host launch latency between the launches
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for i in range(NL):
-            out, st = ops.conv_fwd(x, wpk, 32, 3, 1, in_affine=a, stats=True)
+            out, st = ops.conv_fwd(x, wpk, 32, 3, 1, in_affine=a, stats=True, in_amax=slot, out=buf_out)
     g.replay()
     torch.cuda.synchronize()
     e0.record()
@@ -45,13 +47,13 @@ for label, a in (("fused BN + ReLU input", aff), ("plain input", None)):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / NL
     if reader is None:
-        print("%s: %.3f ms per launch (with its statistics finalize)" % (label, ms))
+        print("%s: %.3f ms per launch (kernel alone)" % (label, ms))
         continue
     nb = min(1024, ops.STREAM_C32_BLOCKS)
     buf = np.zeros((nb, 8), dtype=np.uint64)
     assert reader(buf.ctypes.data, nb) == 0
     s = buf.astype(np.float64)
     life = s[:, 7].mean()
-    print("%s: %.3f ms per launch (with its statistics finalize), %d blocks; block lifetime %.0f ticks of s_memtime" % (label, ms, nb, life))
+    print("%s: %.3f ms per launch (kernel alone), %d blocks; block lifetime %.0f ticks of s_memtime" % (label, ms, nb, life))
     for i, n in enumerate(names):
         print("   %-48s %5.1f %%" % (n, 100.0 * s[:, i].mean() / life))
