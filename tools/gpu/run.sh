@@ -29,7 +29,7 @@ run() {
 FAST="--no-cpu-baseline --no-eer --no-fp32-leg --no-f16-window"
 for step in "$@"; do
     case "$step" in
-        test:all)      run test_all 1100 python3 -m pytest tests -m gpu -x -q ;;
+        test:all)      run test_all 1100 python3 -m pytest tests -m gpu -x -q --durations=25 ;;
         test:*)        run "test_$(echo ${step#test:} | tr -c 'A-Za-z0-9\n' '_')" 900 python3 -m pytest tests -m gpu -x -q -s -k "${step#test:}" ;;
         bench)         run bench 500 python3 bench.py --steps 20 --warmup 5 ;;
         bench_fast)    run bench_fast 300 python3 bench.py --steps 20 --warmup 5 $FAST --no-extra ;;
