@@ -64,6 +64,13 @@ int spk_build_flags(void);
  * the float whose bits the tensor's scale slot holds into [2^14, 2^15).  The slot holds a RIGOROUS upper bound of the tensor's
  * absmax, known before the producer runs (spk_bn_bwd_finalize est_out).  Producers: spk_bn_bwd_apply(pair_scale), and the side
  * output of a fused BatchNorm-backward data gradient (SPK_SIDE_PRESPLIT).  Consumers stage 16-byte groups by plain copy. */
+#define SPK_WGRAD_NOSHIFT (1 << 18) /* spk_conv_wgrad + SPK_WGRAD_GROUPS, 3x3: at stride 1 with TW % 8 == 0 the kernel builds the fragments of
+                                the three taps of a filter row from one 10-pixel window per lane (22 instead of 40 transposed LDS reads per
+                                k-step; bit-identical results); this flag keeps the plain K loop (A/B measurements) */
+#define SPK_WGRAD_M16 (1 << 19) /* spk_conv_wgrad + SPK_WGRAD_GROUPS, 3x3, with SPK_DY_PRESPLIT: conv_wgrad_wm16_kernel - the 2 x 2 wave layout on
+                                v_mfma_f32_16x16x32_f16 (32 pixels per K step), dy brought into LDS by global_load_lds (no registers, no
+                                staging instructions; two LDS buffers).  LDS: halo * 384 + 2 * ceil32(TH * TW) * 256 bytes.  Same products,
+                                another summation order: equal to the other weight gradients within fp32 accumulation error */
 #define SPK_IN_PRESPLIT (1 << 14)    /* spk_conv_mfma: `in` is an f16 pair tensor scaled by the sigma of *in_amax (plain input only) */
 #define SPK_SIDE_PRESPLIT (1 << 15)  /* spk_conv_mfma + SPK_IN_BNBWD: side_draw leaves as an f16 pair tensor (scale: *in_amax) */
 #define SPK_DY_PRESPLIT (1 << 16)    /* spk_conv_wgrad: `dy` is an f16 pair tensor scaled by the sigma of *dy_amax */

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspkhip.so")
 SOURCES = ["err.cpp", "conv_mfma.hip", "conv_wgrad.hip", "stem.hip", "bn.hip", "pool.hip", "gemm.hip", "head.hip",
            "sgd.hip", "score.hip", "conv_split.hip", "conv_wgrad_split.hip", "pack.hip", "conv_pipe.hip", "conv_wgrad_1x1.hip",
-           "conv_wgrad_wm.hip", "conv1x1_stream.hip", "conv3x3_c32_stream.hip"]
+           "conv_wgrad_wm.hip", "conv_wgrad_wm16.hip", "conv1x1_stream.hip", "conv3x3_c32_stream.hip"]
 # kernel forms that were measured and did not pay: producer / consumer convolution and weight gradient,
 # in-wave pipelined weight gradient, in-wave pipelined fused-BatchNorm-backward data gradient.  Kept as source for reference and
 # for the bit-identity tests; compiled only with SPK_EXPERIMENTAL=1 (-DSPK_EXPERIMENTAL; spk_build_flags() & 1)

@@ -55,6 +55,9 @@ static __device__ unsigned long long g_c32_stamps[1024][8];
 #endif
 
 // VAR: 1 = fused input BatchNorm + ReLU, 0 = plain input (compile-time: the staging loop has no branch on it)
+#ifndef C32_XCD_BAND
+#define C32_XCD_BAND 1
+#endif
 template <int VAR>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
@@ -228,7 +231,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
         s_sq += (double)tq;
         C32_T(6);
     };
-    int tile = blockIdx.x;
+    // Virtual block id: block v walks the tiles v, v + G, ...  With C32_XCD_BAND the G / 8 blocks that run on one XCD (the hardware
+    // deals block ids to the eight XCDs in turn) take a contiguous band of virtual ids, i.e. G / 8 neighbouring tiles at a time: the
+    // halo rows and columns they share (10 x 18 pixels staged per 8 x 16 tile: 1.41 x) meet in that XCD's L2 instead of being fetched
+    // from the fabric once per tile.  Tile sets and statistics rows go by the virtual id: results do not depend on the switch.
+    const int vblk = (C32_XCD_BAND && (G & 7) == 0) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    int tile = vblk;
     if (tile < a.ntiles) issue(tile, va, okma);
     if (tile + G < a.ntiles) issue(tile + G, vb, okmb);
     if (C32_DEPTH > 2 && tile + 2 * G < a.ntiles) issue(tile + 2 * G, vc, okmc);
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_stream_kernel(Conv3x3C32Ar
         s_sum += __shfl_xor(s_sum, 32, 64);              // lanes l and l + 32 hold the same channel
         s_sq += __shfl_xor(s_sq, 32, 64);
         if (h == 0) {
-            float* dst = a.stats + ((size_t)(blockIdx.x * 4 + wave) * 32 + r) * 2;
+            float* dst = a.stats + ((size_t)(vblk * 4 + wave) * 32 + r) * 2;
             dst[0] = (float)s_sum;
             dst[1] = (float)s_sq;
         }

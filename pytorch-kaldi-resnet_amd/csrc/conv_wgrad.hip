@@ -18,6 +18,7 @@ int spk_launch_wgrad_split(const WgradArgs& a, int WN, int split, hipStream_t st
 int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);
 int spk_launch_wgrad_pipe(const WgradArgs& a, int WN, hipStream_t st);
 int spk_launch_wgrad_1x1(const WgradArgs& a, int WN, int CG, hipStream_t st);
+int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st);                 // conv_wgrad_wm16.hip: the same on 16x16x32, dy by LDS DMA
 int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st);                   // conv_wgrad_wm.hip: 2 x 2 wave layout (3x3)   // conv_wgrad_1x1.hip: input-channel groups as "taps"      // conv_wgrad_pipe.hip: in-wave pipelined form        // conv_wgrad_split.hip: producer / consumer form
 
 template <int NTAPS, int WK, int WN>
@@ -311,9 +312,10 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     if (flags & SPK_WGRAD_GROUPS) {       // f16x3: bits 12-13 of flags = log2 of the input-channel groups per block
         SPK_REQUIRE(split == 3, "spk_conv_wgrad: the grouped kernels exist in the f16x3 mode");
         const int cg = 1 << ((flags >> 12) & 3);
-        a.flags = flags & (SPK_IN_AFFINE_RELU | SPK_DY_PRESPLIT);
+        a.flags = flags & (SPK_IN_AFFINE_RELU | SPK_DY_PRESPLIT | SPK_WGRAD_NOSHIFT);
         if (ksize == 3) {                 // 3x3: two groups = the 2 x 2 wave layout
             SPK_REQUIRE(cg == 2 && WN == 2, "spk_conv_wgrad: the 3x3 grouped kernel has 2 input-channel groups and WN = 2");
+            if (flags & SPK_WGRAD_M16) return spk_launch_wgrad_wm16(a, (hipStream_t)stream);
             return spk_launch_wgrad_wm(a, (hipStream_t)stream);
         }
         return spk_launch_wgrad_1x1(a, WN, cg, (hipStream_t)stream);

@@ -32,6 +32,14 @@ static __device__ __forceinline__ s16x8 tr_read8(const unsigned char* p0, const 
 // at the same time and re-read the same X and dY tiles, so they are given adjacent places in launch order ON ONE XCD
 // (hardware deals consecutive block ids to the eight XCDs in turn): the re-reads hit that XCD's L2 instead of going to
 // memory Cout/(32 WN) + Cin/32 times (the 1x1 convolutions of the Bottleneck blocks are bound by exactly that traffic).
+// Which slices share an XCD: WGRAD_XCD_BAND = 1 gives every XCD a contiguous BAND of nsplit / 8 slices - slice g walks the regions g,
+// g + nsplit, ..., so at any time an XCD works on nsplit / 8 neighbouring tiles of an image and the halo pixels of their X tiles
+// (1.4-1.56 x the tile) meet in that XCD's L2; 0: slices dealt round-robin (neighbouring tiles on eight different L2s: every halo pixel
+// is fetched from the fabric once per tile that touches it - profiles/pmc_traffic.json before the change).  The slab a slice writes
+// and the regions it sums are the same either way: bit-identical results.
+#ifndef WGRAD_XCD_BAND
+#define WGRAD_XCD_BAND 1
+#endif
 struct WgradBlock { int g, ci0, co0; };
 template <int WN>
 static __device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
@@ -41,7 +49,7 @@ static __device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
     if ((a.nsplit & 7) == 0) {
         const int k = bid >> 3;
         m = k % M;
-        g = (k / M) * 8 + (bid & 7);
+        g = WGRAD_XCD_BAND ? (bid & 7) * (a.nsplit >> 3) + k / M : (k / M) * 8 + (bid & 7);
     } else {
         m = bid % M;
         g = bid / M;

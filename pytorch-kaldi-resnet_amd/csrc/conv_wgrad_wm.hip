@@ -10,10 +10,15 @@
 // would use with WK = 1, but NOT the same summation order as WK = 2 (one accumulator instead of two partial ones), so
 // results agree with conv_wgrad_split_kernel to fp32 rounding, not bit for bit.
 #include "conv_wgrad.h"
+#ifndef WGRAD_XCD_BAND
+#define WGRAD_XCD_BAND 1
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ s16x8 tr_read8m(const unsigned char* p0, const unsigned char* p1) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
@@ -26,7 +31,13 @@ static __device__ __forceinline__ s16x8 tr_read8m(const unsigned char* p0, const
 
 // VAR: compile-time variant of the two run-time switches of the staging pass (so that its per-item branches fold away): bit 0 = fused
 // input BatchNorm + ReLU on X, bit 1 = dY is an f16 pair tensor; VAR < 0: both read from the argument block.
-template <int VAR>
+// SH (stride 1, TW % 8 == 0; experimental): the eight pixels a lane holds of a k-step are consecutive in one tile row, so the fragments
+// of the three taps of a filter row are windows [0,8) [1,9) [2,10) of TEN consecutive halo pixels: pixels [0,8) and [2,10) read as two
+// register quads per term (taps 0 and 2), the middle tap built from both in registers (v_alignbit: 4 per term) - 28 transposed LDS reads
+// per k-step instead of 40, requested one tap ahead.  Same products in the same order: bit-identical to the plain form on the same tile.
+// (A first version with three reads per term and row - 22 per k-step - needed register copies for the unaligned quad of tap 2 and
+// spilled 12-16 registers at the 256-register bound: the reloads sit in the per-region path and cost 25 %.)
+template <int VAR, bool SH>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int NTAPS = 9, KS = 3, WN = 2;
@@ -44,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
         if ((a.nsplit & 7) == 0) {
             const int k = bid >> 3;
             m = k % M;
-            g = (k / M) * 8 + (bid & 7);
+            g = WGRAD_XCD_BAND ? (bid & 7) * (a.nsplit >> 3) + k / M : (k / M) * 8 + (bid & 7);      // conv_wgrad_split.hip: wgrad_block
         } else {
             m = bid % M;
             g = bid / M;
@@ -167,37 +178,91 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm_kernel(WgradArgs a) {
         publish();
         __syncthreads();
         if (region + a.nsplit < a.nregions) prefetch(region + a.nsplit);
-        for (int j = 0; j < nsteps_all; ++j) {
-            int xa[2], da[2];
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const int pix = j * 16 + 8 * h + 4 * blk + q;
-                const int pc = pix < npix ? pix : npix - 1;
-                const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
-                const int lx = pc - ly * a.TW;
-                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + wm * 192 + col_off;
-                da[blk] = pix * PD + wn * 192 + col_off;
-            }
-            s16x8 bf[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) bf[s] = tr_read8m(dys + da[0] + s * 64, dys + da[1] + s * 64);
-            s16x8 a0[2], a1[2];
-            auto load_a = [&](s16x8* af, int t) {
-                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) af[s] = tr_read8m(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+        if constexpr (SH) {
+            // lane -> LDS addresses of k-step j: the X window of its half-step's eight pixels (filter row 0) and its dY fragment
+            auto step_ptrs = [&](int j, const unsigned char*& xr, const unsigned char*& dr) {
+                const int pix0 = j * 16 + 8 * h;
+                const int pc0 = pix0 < npix ? pix0 : npix - 8;          // npix % 8 == 0; the padded half-step multiplies zeros of dY
+                const int ly = (int)__umulhi((unsigned)pc0, a.tw_magic);
+                const int lx0 = pc0 - ly * a.TW;
+                xr = xs + (ly * a.halo_w + lx0 + q) * PX + wm * 192 + col_off;
+                dr = dys + (pix0 + q) * PD + wn * 192 + col_off;
             };
-            load_a(a0, 0);
+            // pixels [0,8) and [2,10) of the window as two aligned register quads per term (taps 0 and 2 need no copies); the middle
+            // tap [1,9) is built from both with four v_alignbit / v_perm per term, in place of the first quad
+            auto load_q = [&](s16x8* af, const unsigned char* p) {
 #pragma unroll
-            for (int t = 0; t < NTAPS; t += 2) {
-                if (t + 1 < NTAPS) load_a(a1, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(acc[t], a0, bf);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 2 < NTAPS) load_a(a0, t + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < NTAPS) mma(acc[t + 1], a1, bf);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < 2; ++s) af[s] = tr_read8m(p + s * 64, p + s * 64 + 4 * PX);
+            };
+            const int row_b = a.halo_w * PX;
+            const unsigned char *xr, *dr;
+            step_ptrs(0, xr, dr);
+            s16x8 bf[2], a0[2], a2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[s] = tr_read8m(dr + s * 64, dr + 4 * PD + s * 64);
+            load_q(a0, xr);
+            load_q(a2, xr + 2 * PX);
+            for (int j = 0; j < nsteps_all; ++j) {
+#pragma unroll
+                for (int ty = 0; ty < KS; ++ty) {
+                    const unsigned char *pn, *dn;
+                    if (ty + 1 < KS) pn = xr + (ty + 1) * row_b;
+                    else step_ptrs(j + 1 < nsteps_all ? j + 1 : j, pn, dn);      // after the last k-step: a harmless re-read
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc[3 * ty], a0, bf);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const u32x4 lo = __builtin_bit_cast(u32x4, a0[s]), hi = __builtin_bit_cast(u32x4, a2[s]);
+                        a0[s] = __builtin_bit_cast(s16x8, (u32x4){__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(lo[2], lo[1], 16),
+                                                                  __builtin_amdgcn_alignbit(lo[3], lo[2], 16), __builtin_amdgcn_alignbit(hi[3], lo[3], 16)});
+                    }
+                    mma(acc[3 * ty + 1], a0, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_q(a0, pn);                                     // the next filter row's first quad, under the products of tap 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc[3 * ty + 2], a2, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ty + 1 == KS) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) bf[s] = tr_read8m(dn + s * 64, dn + 4 * PD + s * 64);
+                    }
+                    load_q(a2, pn + 2 * PX);                            // ... and its second quad under the products of the next tap 0
+                    if (ty + 1 == KS) xr = pn;
+                }
+            }
+        } else {
+            for (int j = 0; j < nsteps_all; ++j) {
+                int xa[2], da[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int pix = j * 16 + 8 * h + 4 * blk + q;
+                    const int pc = pix < npix ? pix : npix - 1;
+                    const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
+                    const int lx = pc - ly * a.TW;
+                    xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + wm * 192 + col_off;
+                    da[blk] = pix * PD + wn * 192 + col_off;
+                }
+                s16x8 bf[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bf[s] = tr_read8m(dys + da[0] + s * 64, dys + da[1] + s * 64);
+                s16x8 a0[2], a1[2];
+                auto load_a = [&](s16x8* af, int t) {
+                    const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s] = tr_read8m(xs + xa[0] + toff + s * 64, xs + xa[1] + toff + s * 64);
+                };
+                load_a(a0, 0);
+#pragma unroll
+                for (int t = 0; t < NTAPS; t += 2) {
+                    if (t + 1 < NTAPS) load_a(a1, t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc[t], a0, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 2 < NTAPS) load_a(a0, t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < NTAPS) mma(acc[t + 1], a1, bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -223,12 +288,21 @@ int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st) {
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
     const int var = ((a.flags & SPK_IN_AFFINE_RELU) ? 1 : 0) | ((a.flags & SPK_DY_PRESPLIT) ? 2 : 0);
+    // the shifted-window K loop (SH): stride 1, tile rows of whole 8-pixel half-steps.  Bit-identical and measured +-0 inside the step
+    // (28 instead of 40 transposed reads per k-step change nothing: DESIGN.md section 7b) - compiled with SPK_EXPERIMENTAL only;
+    // SPK_WGRAD_NOSHIFT keeps the plain form there (A/B)
+#ifdef SPK_EXPERIMENTAL
+    const bool sh = a.S == 1 && a.TW % 8 == 0 && !(a.flags & SPK_WGRAD_NOSHIFT);
+    if (var == 3 && sh) hipLaunchKernelGGL((conv_wgrad_wm_kernel<3, true>), grid, dim3(256), lds_bytes, st, a);
+    else if (var == 2 && sh) hipLaunchKernelGGL((conv_wgrad_wm_kernel<2, true>), grid, dim3(256), lds_bytes, st, a);
+    else
+#endif
 #ifdef SPK_NO_FL_VARIANTS
-    hipLaunchKernelGGL(conv_wgrad_wm_kernel<-1>, grid, dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv_wgrad_wm_kernel<-1, false>), grid, dim3(256), lds_bytes, st, a);
 #else
-    if (var == 3) hipLaunchKernelGGL(conv_wgrad_wm_kernel<3>, grid, dim3(256), lds_bytes, st, a);
-    else if (var == 2) hipLaunchKernelGGL(conv_wgrad_wm_kernel<2>, grid, dim3(256), lds_bytes, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_wm_kernel<-1>, grid, dim3(256), lds_bytes, st, a);
+    if (var == 3) hipLaunchKernelGGL((conv_wgrad_wm_kernel<3, false>), grid, dim3(256), lds_bytes, st, a);
+    else if (var == 2) hipLaunchKernelGGL((conv_wgrad_wm_kernel<2, false>), grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_wm_kernel<-1, false>), grid, dim3(256), lds_bytes, st, a);
 #endif
     SPK_LAUNCH_CHECK("spk_conv_wgrad(2x2 waves)");
     return 0;

@@ -1,0 +1,269 @@
+// 3x3 weight gradient, f16x3 operands, 2 x 2 wave layout (as conv_wgrad_wm.hip) on v_mfma_f32_16x16x32_f16, with dY - an f16 pair
+// tensor - brought into LDS by the DMA path (global_load_lds_dwordx4), never through registers.
+//
+// Why: conv_wgrad_wm_kernel runs at 85 % of what its bare K loop reaches on the 32x32x16 shape at the board's power cap
+// (tools/probe/shape_probe.hip, two waves per SIMD: 1 232 TFLOP/s of fp16 issue = 0.277 ms for one launch's products; the kernel takes
+// 0.32-0.33 ms) - the 16x16x32 shape holds a higher clock (1 545 TFLOP/s in the same probe).  A first 16x16x32 form of that kernel
+// (round 4, not kept) spilled: a k-step of 32 pixels doubles the fragment registers (A 16 + B 16 instead of 8 + 8 + 8 for the double
+// buffer) at the 256-register bound, and a spilled register is reloaded once per REGION here (64 pixels = 1.6 us of matrix
+// instructions).  The registers come from the dY prefetch: a pair tensor is staged by plain copy, so its 16 KB per region go global ->
+// LDS directly (two LDS buffers, the next region's tile in flight under the K loop of the current one) and the 16 prefetch registers
+// and the dY half of the publish pass disappear.
+//
+// LDS image of dY (per buffer): chunks of 4 consecutive tile pixels x 64 channels = 1024 bytes = one wave-instruction of the DMA path
+// (a lane's 16 bytes land at base + 16 lane).  A piece = the [4 x fp16 high][4 x fp16 low] of 4 channels of one pixel, as stored in
+// the pair tensor.  Inside a chunk piece (pixel q, channel group c = 0..15) sits in slot (c >> 2) * 16 + (c & 3) * 4 + q: the sixteen
+// lanes of one ds_read_b64_tr_b16 group read pixels q = 0..3 x channel groups (c & 3) = 0..3 of one 16-channel tile - sixteen
+// different 16-byte slots of one 256-byte row: no bank conflict.  The DMA lane L therefore fetches pixel L & 3, channel group
+// ((L >> 4) << 2) | ((L >> 2) & 3); pixels outside the image (ragged edge tiles, the padding of the last k-step) fetch a 16-byte block
+// of zeros instead.
+//
+// Products and scales as conv_wgrad_wm_kernel; summation order differs (32 pixels per matrix instruction, the term-1 x term-0 product
+// first): equal to the other weight-gradient kernels within fp32 accumulation error, not bit for bit.
+#include "conv_wgrad.h"
+#ifndef WGRAD_XCD_BAND
+#define WGRAD_XCD_BAND 1
+#endif
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+static __device__ __forceinline__ s16x8 tr_read8w(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __attribute__((aligned(16))) unsigned g_wm16_zero[4];      // what the DMA lanes of pixels outside the image fetch
+
+#define WM16_NX 7      // X halo float4 per thread: halo_pix <= 16 * WM16_NX pixels of 64 channels
+
+// VAR: bit 0 = fused input BatchNorm + ReLU on X (compile-time, as conv_wgrad_wm_kernel); dY is always an f16 pair tensor
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    constexpr int NTAPS = 9, KS = 3;
+    constexpr int PX = 2 * 192;                           // X bytes per staged pixel: [2 groups][3-term pitch][32 ch fp16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int g, ci0, co0;                                      // block -> (region slice, channel groups): conv_wgrad_split.hip, wgrad_block
+    {
+        const int ncgi = a.Cin >> 6, M = ncgi * (a.Cout >> 6);
+        const int bid = blockIdx.x;
+        int m;
+        if ((a.nsplit & 7) == 0) {
+            const int k = bid >> 3;
+            m = k % M;
+            g = WGRAD_XCD_BAND ? (bid & 7) * (a.nsplit >> 3) + k / M : (k / M) * 8 + (bid & 7);
+        } else {
+            m = bid % M;
+            g = bid / M;
+        }
+        ci0 = (m % ncgi) * 64;
+        co0 = (m / ncgi) * 64;
+    }
+    const int halo_pix = a.halo_h * a.halo_w;
+    const int npix = a.TH * a.TW;
+    const int nsteps = (npix + 31) >> 5;                  // k-steps of 32 pixels; the padding pixels of dY are zero
+    const int nchunks = nsteps << 3;                      // 4-pixel chunks of a dY buffer
+    unsigned char* xs = ldsb;
+    unsigned char* dys = ldsb + halo_pix * PX;            // two buffers of nchunks * 1024 bytes
+    const int dbuf = nchunks << 10;
+    const float sig_x = spk_sigma_from_amax_bits(*a.x_amax);
+    const float sig_d = spk_sigma_from_amax_bits(*a.dy_amax);
+
+    f32x4 acc[NTAPS][2][2];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q16 = tid & 15;                             // this thread's float4 of the 64 channels of an X pixel
+    f32x4 px[WM16_NX];
+    unsigned inx = 0;
+    const unsigned x_row = (unsigned)a.IW * a.Cin * 4u, x_px = (unsigned)a.Cin * 4u;
+    const unsigned d_row = (unsigned)a.OW * a.Cout * 4u, d_px = (unsigned)a.Cout * 4u;
+    const unsigned x_c = (unsigned)(ci0 + q16 * 4) * 4u;
+    const unsigned d_c = (unsigned)(co0 + ((((lane >> 4) << 2) | ((lane >> 2) & 3)) << 2)) * 4u;     // the DMA lane's channel group
+    auto region_origin = [&](int region, int& b, int& oy0, int& ox0) {
+        int pt = region;
+        const int tx = pt % a.tiles_x;
+        pt /= a.tiles_x;
+        const int ty = pt % a.tiles_y;
+        b = pt / a.tiles_y;
+        oy0 = ty * a.TH;
+        ox0 = tx * a.TW;
+    };
+    auto prefetch_x = [&](int region) {
+        int b, oy0, ox0;
+        region_origin(region, b, oy0, ox0);
+        const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
+        const char* xb = (const char*)(a.x + (size_t)b * a.IH * a.IW * a.Cin);
+        const unsigned x_safe = (unsigned)(oy0 * a.S) * x_row + (unsigned)(ox0 * a.S) * x_px + x_c;
+        inx = 0;
+#pragma unroll
+        for (int u = 0; u < WM16_NX; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
+            const int hx = p - hy * a.halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW && p < halo_pix;
+            if (ok) inx |= 1u << u;
+            const unsigned off = ok ? (unsigned)iy * x_row + (unsigned)ix * x_px + x_c : x_safe;
+            px[u] = wgrad_ld<2>(xb + off);
+        }
+    };
+    // the dY tile of a region, global -> LDS buffer `buf`: wave w brings chunks w, w + 4, ...
+    auto dma_dy = [&](int region, int buf) {
+        int b, oy0, ox0;
+        region_origin(region, b, oy0, ox0);
+        const char* db = (const char*)(a.dy + (size_t)b * a.OH * a.OW * a.Cout);
+        unsigned char* dst = dys + buf * dbuf;
+        for (int ch = wave; ch < nchunks; ch += 4) {
+            const int p = 4 * ch + (lane & 3);
+            const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
+            const int lx = p - ly * a.TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            const bool ok = p < npix && oy < a.OH && ox < a.OW;
+            const char* src = ok ? db + ((unsigned)oy * d_row + (unsigned)ox * d_px + d_c) : (const char*)g_wm16_zero;
+            // (as inline assembly: the compiler models the builtin as a store to LDS through the vector-memory counter and puts s_waitcnt
+            // vmcnt(0) in front of every later LDS read - the fragment reads of the CURRENT buffer at the top of each k-step - which waits
+            // for the whole prefetch.  The buffers alternate; the vmcnt(0) that matters is the explicit one before the barrier below.
+            // Vector-memory operations return in order, so the compiler's own vmcnt arithmetic for the X loads stays on the safe side.)
+            const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + (ch << 10));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(src) : "memory", "m0");
+        }
+    };
+    auto publish_x = [&]() {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if constexpr ((VAR & 1) != 0) {
+            sc = *(const f32x4*)(a.in_scale + ci0 + q16 * 4);
+            sh = *(const f32x4*)(a.in_shift + ci0 + q16 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < WM16_NX; ++u) {
+            const int p = (tid >> 4) + 16 * u;
+            f32x4 w = px[u];
+            if constexpr ((VAR & 1) != 0) {
+                w = w * sc + sh;
+                w[0] = fmaxf(w[0], 0.f);
+                w[1] = fmaxf(w[1], 0.f);
+                w[2] = fmaxf(w[2], 0.f);
+                w[3] = fmaxf(w[3], 0.f);
+            }
+            if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < halo_pix) {
+                uint2* dst = (uint2*)(xs + p * PX + (q16 >> 3) * 192) + (q16 & 7);
+                uint2 t0, t1;
+                split2h(w, sig_x, t0, t1);
+                dst[0] = t0;
+                dst[8] = t1;
+            }
+        }
+    };
+
+    // 16 x 16 x 32 operands: lane = row (A: input channel) or column (B: output channel) lane & 15, pixels 8 (lane >> 4) .. + 7 of the step.
+    // One transposed read hands a lane 4 pixels of its channel from the 16 lanes (pixel q, 4-channel piece p4) of its group.
+    const int kg = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int a_lane = wm * 192 + p4 * 8;                                  // X: [group wm][term][32 ch]: row tile rt at + 32 rt, term s at + 64 s
+    const int d_lane = (2 * kg) * 1024 + wn * 512 + p4 * 64 + q * 16;      // dY: chunk 2 kg (+ 1), slot (2 wn + ct) * 16 + 4 p4 + q, term s at + 8 s
+
+    int region = g, buf = 0;
+    if (region < a.nregions) {
+        dma_dy(region, 0);                                // (before the X loads: older operations complete first, the compiler's counts for px stay exact)
+        prefetch_x(region);
+    }
+    for (; region < a.nregions; region += a.nsplit, buf ^= 1) {
+        __syncthreads();                                  // every wave is past the previous region's K loop
+        publish_x();
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this region's dY tile has landed in LDS
+        __syncthreads();
+        if (region + a.nsplit < a.nregions) {
+            dma_dy(region + a.nsplit, buf ^ 1);           // last read by the K loop of the region before this one
+            prefetch_x(region + a.nsplit);
+        }
+        const unsigned char* dcur = dys + buf * dbuf + d_lane;
+        for (int j = 0; j < nsteps; ++j) {
+            s16x8 bf[2][2];                               // [column tile][term]
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bf[ct][s] = tr_read8w(dcur + (j << 13) + ct * 256 + s * 8, dcur + (j << 13) + 1024 + ct * 256 + s * 8);
+            int xa[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int pix = j * 32 + 8 * kg + 4 * blk + q;
+                const int pc = pix < npix ? pix : npix - 1;
+                const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
+                const int lx = pc - ly * a.TW;
+                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + a_lane;
+            }
+            s16x8 af[2][2];                               // [term][row tile]
+            auto load_a = [&](int s, int t) {
+                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX + s * 64;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) af[s][rt] = tr_read8w(xs + xa[0] + toff + rt * 32, xs + xa[1] + toff + rt * 32);
+            };
+            auto mm = [&](int t, int sa, int sb) {        // four independent accumulators in rotation
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[t][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[sa][rt]), __builtin_bit_cast(f16x8, bf[ct][sb]),
+                                                                                acc[t][rt][ct], 0, 0, 0);
+            };
+            load_a(1, 0);
+            load_a(0, 0);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                // term 1 of A is used by one product only: its registers take the next tap's term 1 under the other two products,
+                // term 0 follows under the next tap's first product
+                __builtin_amdgcn_sched_barrier(0);
+                mm(t, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) load_a(1, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(t, 0, 1);
+                mm(t, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) load_a(0, t + 1);
+            }
+        }
+    }
+
+    float* slab = a.partial + (size_t)g * NTAPS * a.Cin * a.Cout;
+    const float inv = (1.f / sig_x) * (1.f / sig_d);
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = rt * 16 + 4 * kg + e, col = ct * 16 + (lane & 15);       // 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + e
+                    slab[((size_t)t * a.Cin + ci0 + wm * 32 + row) * a.Cout + co0 + wn * 32 + col] = acc[t][rt][ct][e] * inv;
+                }
+}
+
+size_t spk_wgrad_wm16_lds_bytes(int halo_pix, int npix) { return (size_t)halo_pix * 384 + 2 * (size_t)(((npix + 31) >> 5) << 5) * 256; }
+
+int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st) {
+    SPK_REQUIRE(a.KW == 3 && a.Cin % 64 == 0 && a.Cout % 64 == 0, "spk_conv_wgrad(2x2 waves, 16x16x32): 3x3, Cin and Cout multiples of 64 (%d, %d)", a.Cin, a.Cout);
+    SPK_REQUIRE(a.flags & SPK_DY_PRESPLIT, "spk_conv_wgrad(2x2 waves, 16x16x32): dy must be an f16 pair tensor (SPK_DY_PRESPLIT): it is staged by the DMA path");
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 16 * WM16_NX, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d (halo %dx%d) exceeds the prefetch window", a.TH, a.TW,
+                a.halo_h, a.halo_w);
+    SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
+                "spk_conv_wgrad(2x2 waves, 16x16x32): an image exceeds 32-bit byte offsets");
+    const size_t lds_bytes = spk_wgrad_wm16_lds_bytes(a.halo_h * a.halo_w, a.TH * a.TW);
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
+    dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
+    if (a.flags & SPK_IN_AFFINE_RELU) hipLaunchKernelGGL(conv_wgrad_wm16_kernel<1>, grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_wm16_kernel<0>, grid, dim3(256), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_wgrad(2x2 waves, 16x16x32)");
+    return 0;
+}

@@ -42,7 +42,9 @@ enum {
     SPK_IN_PRESPLIT = 1 << 14,    // spk_conv_mfma: `in` holds f16 pairs scaled by the sigma of in_amax (no input transform)
     SPK_SIDE_PRESPLIT = 1 << 15,  // spk_conv_mfma + IN_BNBWD: side_draw is written as f16 pairs (scale: the sigma of in_amax)
     SPK_DY_PRESPLIT = 1 << 16,    // spk_conv_wgrad: `dy` holds f16 pairs scaled by the sigma of dy_amax
-    SPK_CONV_M16 = 1 << 17        // with SPK_CONV_PIPE: the v_mfma_f32_16x16x32_f16 form of the pipelined kernel (taps paired per K step)
+    SPK_CONV_M16 = 1 << 17,       // with SPK_CONV_PIPE: the v_mfma_f32_16x16x32_f16 form of the pipelined kernel (taps paired per K step)
+    SPK_WGRAD_NOSHIFT = 1 << 18,  // spk_conv_wgrad, 3x3 grouped kernel: keep the plain K loop where the shifted-window form applies (A/B)
+    SPK_WGRAD_M16 = 1 << 19       // spk_conv_wgrad, 3x3 grouped kernel with a pair-tensor dy: the v_mfma_f32_16x16x32_f16 form, dy by LDS DMA
 };
 
 static inline int spk_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -13,6 +13,8 @@ CONV_PIPE = 1024
 WGRAD_GROUPS = 2048        # spk_conv_wgrad flags: 1x1 f16x3 kernel with 1 << (bits 12-13) input-channel groups per block
 IN_PRESPLIT, SIDE_PRESPLIT, DY_PRESPLIT = 1 << 14, 1 << 15, 1 << 16     # f16 pair tensors (include/spkhip.h)
 CONV_M16 = 1 << 17      # 16x16x32 form of the pipelined convolution
+WGRAD_NOSHIFT = 1 << 18  # 3x3 grouped weight gradient: plain K loop instead of the shifted-window form (A/B)
+WGRAD_M16 = 1 << 19      # 3x3 grouped weight gradient on 16x16x32 with dy (a pair tensor) staged by LDS DMA
 MASK_NONE, MASK_ACT, MASK_RAW, MASK_BITS = 0, 1, 2, 3
 
 _P = ctypes.c_void_p

@@ -159,6 +159,8 @@ PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
 # 0.75 vs 0.81 ms (64 channels) and 0.50 vs 0.54 ms (128 channels, against the wave-specialised kernel), nothing measurable per step
 PIPE_BNBWD = os.environ.get("SPK_PIPE_BNBWD", "0") == "1"
 GROUPED_1X1 = os.environ.get("SPK_WGRAD_1X1_GROUPS", "1") == "1"   # 1x1 weight gradients: input-channel groups as "taps"
+WM16 = os.environ.get("SPK_WM16", "1") == "1"             # 3x3 grouped weight gradient with a pair-tensor dy: 16x16x32 form, dy by LDS DMA (csrc/conv_wgrad_wm16.hip)
+WM_SHIFT = os.environ.get("SPK_WM_SHIFT", "1") == "1"      # 3x3 grouped weight gradient: shifted-window K loop where it applies (csrc/conv_wgrad_wm.hip, SH)
 GROUPED_3X3 = os.environ.get("SPK_WGRAD_3X3_GROUPS", "1") == "1"   # 3x3 weight gradients: 2 x 2 (cin group x cout group) wave layout
 GROUPED_1X1_BLOCKS = int(os.environ.get("SPK_WGRAD_1X1_BLOCKS", "512"))
 PIPE_MIN_CIN = int(os.environ.get("SPK_PIPE_MIN_CIN", "64"))    # 32 channels = two chunks: nothing to pipeline, and the second tile costs occupancy
@@ -643,6 +645,7 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     # 3x3, f16x3: 2 input-channel groups x 2 output-channel groups of waves (csrc/conv_wgrad_wm.hip)
     wm = (GROUPED_3X3 and not wgws and not wgp and split == 3 and ksize == 3 and WN == 2 and Cin % 64 == 0 and Cout % 64 == 0
           and halo <= 112 and TH * TW <= 64 and halo * 384 + -(-(TH * TW) // 16) * 16 * 448 <= 80 * 1024)
+    wm16 = wm and WM16 and dy_presplit and halo * 384 + 2 * -(-(TH * TW) // 32) * 32 * 256 <= 80 * 1024
     if wm:
         cg = 2
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else (GROUPED_1X1_BLOCKS if cg else None),
@@ -654,11 +657,15 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
         flags |= WGRAD_GROUPS | ({2: 1, 4: 2}[cg] << 12)
     if dy_presplit:
         flags |= DY_PRESPLIT
+    if wm and not WM_SHIFT:
+        flags |= hip.WGRAD_NOSHIFT
+    if wm16:
+        flags |= hip.WGRAD_M16
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_wm_kernel" if wm
+         label=("conv_wgrad_wm16_kernel" if wm16 else "conv_wgrad_wm_kernel" if wm
          else ("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
          else ("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
          else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp

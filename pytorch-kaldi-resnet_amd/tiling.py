@@ -191,8 +191,17 @@ def conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout, mode=0, split=0):
     return _conv_tile(*key)
 
 
+# ... and SPK_WGRAD_TILE="OH,OW,Cin,Cout,ksize,stride:TH,TW,WN" the weight-gradient tile of a shape (entries separated by ';')
+_WGRAD_TILE_OVERRIDE = {}
+for _e in filter(None, _os.environ.get("SPK_WGRAD_TILE", "").split(";")):
+    _k, _v = _e.split(":")
+    _WGRAD_TILE_OVERRIDE[tuple(int(x) for x in _k.split(","))] = tuple(int(x) for x in _v.split(","))
+
+
 def wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=0):
     key = (OH, OW, Cin, Cout, ksize, stride)
+    if key in _WGRAD_TILE_OVERRIDE:
+        return _WGRAD_TILE_OVERRIDE[key]
     if split and key in FORCE_WGRAD_SPLIT:
         return FORCE_WGRAD_SPLIT[key]
     if key in FORCE_WGRAD:

@@ -16,3 +16,37 @@ def hip_relu_masks(eng, saved):
     if "h" in saved["head"]:
         masks.append((saved["head"]["h"] > 0).cpu())
     return masks
+
+
+# ---- f16 pair tensors and scale slots of the f16x3 operand mode (host restatements used by the kernel tests)
+def slot():
+    return torch.zeros(1, device="cuda", dtype=torch.int32)
+
+
+def sigma_of(slot_t):
+    """host copy of spk_sigma_from_amax_bits"""
+    bits = int(slot_t.cpu().view(torch.int32)[0]) & 0xFFFFFFFF
+    e = (bits >> 23) & 0xFF
+    if e in (0, 255):
+        return 1.0
+    return 2.0 ** (14 - (e - 127))
+
+
+def slot_value(slot_t):
+    return float(slot_t.cpu().view(torch.float32)[0])
+
+
+def encode_pairs(t32, sig):
+    """host restatement of split2h + the pair layout: [.., 4k..4k+3] floats -> [4 x fp16 hi][4 x fp16 lo] of value * sigma"""
+    u = (t32.double() * sig).float().clamp(-65504.0, 65504.0)       # sigma is a power of two: exact
+    hi = u.half()
+    lo = (u - hi.float()).half()
+    g = t32.shape[-1] // 4
+    hi = hi.reshape(-1, g, 4)
+    lo = lo.reshape(-1, g, 4)
+    return torch.cat([hi, lo], dim=-1).reshape(-1).view(torch.float32).reshape(t32.shape)
+
+
+def decode_pairs(tp, sig):
+    h = tp.reshape(-1).view(torch.float16).reshape(-1, 8)
+    return ((h[:, :4].double() + h[:, 4:].double()) / sig).reshape(tp.shape)

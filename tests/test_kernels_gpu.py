@@ -852,6 +852,126 @@ def test_scoring_backend_on_device(ops, gold_dir, tmp_path):
         ops.topk_mean_std(x, 6)
 
 
+@pytest.mark.parametrize("shape,tile", [
+    ((3, 64, 64, 40, 150, 1), (8, 8)),        # the step's own shapes and tiles (tile_table.json) ...
+    ((3, 128, 128, 20, 75, 1), (4, 16)),
+    ((2, 256, 256, 10, 38, 1), (10, 6)),      # ... 60 pixels = 1.9 k-steps: the padding pixels fetch the zero block
+    ((2, 64, 128, 40, 150, 2), (3, 6)),       # stride 2 (halo 7 x 13): 18 pixels, one k-step, almost half of it padding
+    ((2, 64, 128, 13, 29, 1), (2, 24)),       # ragged right / bottom edges
+    ((2, 128, 64, 3, 5, 1), (4, 16)),         # an image smaller than one tile
+    ((5, 64, 64, 9, 33, 1), (3, 10)),         # tile width not a multiple of 4: the four pixels of a DMA chunk straddle tile rows
+])
+def test_weight_gradient_16x16x32_with_dy_by_lds_dma(ops, shape, tile):
+    """conv_wgrad_wm16_kernel (csrc/conv_wgrad_wm16.hip; the default for the 3x3 weight gradients with Cin, Cout multiples of 64 whose dY
+    is an f16 pair tensor): the 2 x 2 wave layout on v_mfma_f32_16x16x32_f16, dY brought into a swizzled, double-buffered LDS image by
+    global_load_lds.  Same products as conv_wgrad_wm_kernel in another summation order: equal within fp32 accumulation error (2e-6 of
+    the largest element), as close to the fp64 gradient, with and without the fused BatchNorm + ReLU on X and with accumulation.
+    Reference semantics: autograd of nn.Conv2d (scripts/model.py:41-44 under scripts/train_resnet.py:327 loss.backward())."""
+    from helpers import encode_pairs, sigma_of, slot
+    from pytorch_kaldi_resnet_amd import tiling
+    B, Cin, Cout, H, Wd, stride = shape
+    OH, OW = ops.conv_out_hw(H, Wd, 3, stride)
+    key = (OH, OW, Cin, Cout, 3, stride)
+    old_force, old_wm16, old_split = tiling.FORCE_WGRAD_SPLIT.get(key), ops.WM16, ops.SPLIT
+    tiling.FORCE_WGRAD_SPLIT[key] = (tile[0], tile[1], 2)
+    ops.SPLIT = ops.MFMA_MODES["f16x3"]
+    try:
+        x = rnd(31, B, H, Wd, Cin).cuda()
+        dy = (rnd(32, B, OH, OW, Cout, scale=3e-4) * (1 + 50 * (rnd(33, B, OH, OW, 1) > 0.97))).cuda()
+        sc, sh = rnd(34, Cin, scale=0.4, shift=1.0).cuda(), rnd(35, Cin, scale=0.3).cuda()
+        dy_amax = ops.absmax_into(dy, slot())
+        x_amax = ops.absmax_into(x, slot())
+        xa_amax = ops.absmax_into(torch.relu(x * sc + sh), slot())
+        dy_p = encode_pairs(dy.cpu(), sigma_of(dy_amax)).cuda()
+        res = {}
+        for m16 in (True, False):
+            ops.WM16 = m16
+            dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw, 3, stride, dy_amax=dy_amax, x_amax=x_amax, dy_presplit=True)
+            dw2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw2, 3, stride, in_affine=(sc, sh), accumulate=True, dy_amax=dy_amax, x_amax=xa_amax, dy_presplit=True)
+            dw3 = torch.empty(Cout, Cin, 3, 3, device="cuda")       # a second launch: both LDS buffers and the zero block reused
+            ops.conv_wgrad(x, dy_p, dw3, 3, stride, dy_amax=dy_amax, x_amax=x_amax, dy_presplit=True)
+            res[m16] = (dw, dw2, dw3)
+        torch.cuda.synchronize()
+        assert torch.equal(res[True][0], res[True][2]), "not deterministic"
+        xc, dc = x.cpu().permute(0, 3, 1, 2).double(), dy.cpu().permute(0, 3, 1, 2).double()
+        ref = torch.nn.grad.conv2d_weight(xc, (Cout, Cin, 3, 3), dc, stride=stride, padding=1)
+        xa = torch.relu(xc * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1))
+        ref2 = torch.nn.grad.conv2d_weight(xa, (Cout, Cin, 3, 3), dc, stride=stride, padding=1)
+        e16, e32 = [(res[m][0].double().cpu() - ref).norm() / ref.norm() for m in (True, False)]
+        print("shape %s tile %s: |dw - fp64| / |fp64| = %.2e (16x16x32, dY by DMA)  %.2e (32x32x16)" % (shape, tile, e16, e32))
+        assert e16 < 1e-5 and e16 < 2 * e32 + 1e-7, (e16, e32)
+        assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-6 * float(ref.abs().max())
+        d2 = (res[True][1].double().cpu() - 0.25) - ref2
+        assert d2.norm() <= 1e-5 * ref2.norm() + 1.5e-8 * ref2.numel() ** 0.5
+        assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 3e-8
+    finally:
+        ops.WM16, ops.SPLIT = old_wm16, old_split
+        if old_force is None:
+            tiling.FORCE_WGRAD_SPLIT.pop(key, None)
+        else:
+            tiling.FORCE_WGRAD_SPLIT[key] = old_force
+
+
+@pytest.mark.parametrize("shape,tile", [
+    ((3, 64, 64, 40, 150), (8, 8)),        # the step's own tiles (tile_table.json) ...
+    ((3, 128, 128, 20, 75), (4, 16)),
+    ((2, 256, 256, 10, 38), (5, 8)),       # ... 40 pixels = 2.5 k-steps: the padded half-step multiplies zeros of dY
+    ((2, 64, 128, 13, 29), (2, 24)),       # ragged right / bottom edges, three half-steps per tile row
+    ((2, 128, 64, 3, 5), (4, 16)),         # an image smaller than one tile
+    ((1, 64, 64, 9, 33), (1, 32)),         # one-row tiles: the third window read of the last halo row reaches past the X image in LDS
+])
+def test_shifted_window_weight_gradient_is_bit_identical_to_the_plain_k_loop(ops, shape, tile):
+    """conv_wgrad_wm_kernel<VAR, SH> (csrc/conv_wgrad_wm.hip): at stride 1 with TW % 8 == 0 the fragments of the three taps of a filter
+    row come from one 10-pixel window per lane (22 instead of 40 transposed LDS reads per k-step, the middle tap built in registers).
+    Measured +-0 inside the training step: compiled only with SPK_EXPERIMENTAL.
+    Same products in the same order as the plain K loop (SPK_WGRAD_NOSHIFT) on the same tile: the weight gradients are bit-identical,
+    with and without the fused BatchNorm + ReLU on X, and they are the gradients autograd gives (reference: scripts/model.py:41-44
+    nn.Conv2d under scripts/train_resnet.py:327 loss.backward())."""
+    needs_experimental()
+    from helpers import encode_pairs, sigma_of, slot
+    from pytorch_kaldi_resnet_amd import tiling
+    B, Cin, Cout, H, Wd = shape
+    key = (H, Wd, Cin, Cout, 3, 1)
+    old_force, old_shift, old_split = tiling.FORCE_WGRAD_SPLIT.get(key), ops.WM_SHIFT, ops.SPLIT
+    tiling.FORCE_WGRAD_SPLIT[key] = (tile[0], tile[1], 2)
+    ops.SPLIT = ops.MFMA_MODES["f16x3"]
+    try:
+        x = rnd(21, B, H, Wd, Cin).cuda()
+        dy = (rnd(22, B, H, Wd, Cout, scale=3e-4) * (1 + 50 * (rnd(23, B, H, Wd, 1) > 0.97))).cuda()
+        sc, sh = rnd(24, Cin, scale=0.4, shift=1.0).cuda(), rnd(25, Cin, scale=0.3).cuda()
+        dy_amax = ops.absmax_into(dy, slot())
+        x_amax = ops.absmax_into(x, slot())
+        xa_amax = ops.absmax_into(torch.relu(x * sc + sh), slot())
+        dy_p = encode_pairs(dy.cpu(), sigma_of(dy_amax)).cuda()
+        res = {}
+        for shift in (True, False):
+            ops.WM_SHIFT = shift
+            dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw, 3, 1, dy_amax=dy_amax, x_amax=x_amax, dy_presplit=True)
+            dw2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw2, 3, 1, in_affine=(sc, sh), accumulate=True, dy_amax=dy_amax, x_amax=xa_amax, dy_presplit=True)
+            res[shift] = (dw, dw2)
+        torch.cuda.synchronize()
+        assert torch.equal(res[True][0], res[False][0]), "plain X"
+        assert torch.equal(res[True][1], res[False][1]), "fused BatchNorm + ReLU on X"
+        xc, dc = x.cpu().permute(0, 3, 1, 2).double(), dy.cpu().permute(0, 3, 1, 2).double()
+        ref = torch.nn.grad.conv2d_weight(xc, (Cout, Cin, 3, 3), dc, stride=1, padding=1)
+        assert (res[True][0].double().cpu() - ref).norm() / ref.norm() < 1e-5
+        xa = torch.relu(xc * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1))
+        ref2 = torch.nn.grad.conv2d_weight(xa, (Cout, Cin, 3, 3), dc, stride=1, padding=1)
+        # accumulated onto 0.25: every element also carries the rounding of that sum (half an ulp of 0.25 = 1.5e-8)
+        d2 = (res[True][1].double().cpu() - 0.25) - ref2
+        assert d2.norm() <= 1e-5 * ref2.norm() + 1.5e-8 * ref2.numel() ** 0.5
+    finally:
+        ops.WM_SHIFT, ops.SPLIT = old_shift, old_split
+        if old_force is None:
+            tiling.FORCE_WGRAD_SPLIT.pop(key, None)
+        else:
+            tiling.FORCE_WGRAD_SPLIT[key] = old_force
+
+
 def test_experimental_kernel_forms_in_their_variant_library():
     """The producer / consumer convolution and weight gradient, the in-wave pipelined weight gradient and the in-wave pipelined
     fused-BatchNorm-backward data gradient were measured and did not pay; they are compiled only with
@@ -867,13 +987,13 @@ def test_experimental_kernel_forms_in_their_variant_library():
     if not os.path.exists(lib):
         pytest.skip("variants/libspkhip_exp.so not built (python __graft_entry__.py build)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "wave_specialised or pipelined_conv"], env=dict(os.environ, SPK_LIB=lib), capture_output=True, text=True,
+                        "wave_specialised or pipelined_conv or shifted_window"], env=dict(os.environ, SPK_LIB=lib), capture_output=True, text=True,
                        timeout=900)
     tail = r.stdout[-1500:] + r.stderr[-500:]
     assert r.returncode == 0, tail
     import re
     m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) >= 30, tail                  # 28 + 5 + 6 cases; a few layouts skip themselves by design
+    assert m and int(m.group(1)) >= 36, tail                  # 28 + 5 + 6 + 6 cases; a few layouts skip themselves by design
 
 
 

@@ -40,37 +40,7 @@ def rnd(seed, *shape, scale=1.0, shift=0.0):
     return torch.from_numpy(((W.hash_uniform(seed, 1, n) * 2 - 1) * scale + shift).astype(np.float32).reshape(shape))
 
 
-def slot():
-    return torch.zeros(1, device="cuda", dtype=torch.int32)
-
-
-def sigma_of(slot_t):
-    """host copy of spk_sigma_from_amax_bits"""
-    bits = int(slot_t.cpu().view(torch.int32)[0]) & 0xFFFFFFFF
-    e = (bits >> 23) & 0xFF
-    if e in (0, 255):
-        return 1.0
-    return 2.0 ** (14 - (e - 127))
-
-
-def slot_value(slot_t):
-    return float(slot_t.cpu().view(torch.float32)[0])
-
-
-def encode_pairs(t32, sig):
-    """host restatement of split2h + the pair layout: [.., 4k..4k+3] floats -> [4 x fp16 hi][4 x fp16 lo] of value * sigma"""
-    u = (t32.double() * sig).float().clamp(-65504.0, 65504.0)       # sigma is a power of two: exact
-    hi = u.half()
-    lo = (u - hi.float()).half()
-    g = t32.shape[-1] // 4
-    hi = hi.reshape(-1, g, 4)
-    lo = lo.reshape(-1, g, 4)
-    return torch.cat([hi, lo], dim=-1).reshape(-1).view(torch.float32).reshape(t32.shape)
-
-
-def decode_pairs(tp, sig):
-    h = tp.reshape(-1).view(torch.float16).reshape(-1, 8)
-    return ((h[:, :4].double() + h[:, 4:].double()) / sig).reshape(tp.shape)
+from helpers import decode_pairs, encode_pairs, sigma_of, slot, slot_value  # noqa: E402,F401
 
 
 SHAPES = [
@@ -130,9 +100,16 @@ def test_pair_tensor_paths_equal_the_fp32_draw_paths_bit_for_bit(ops, shape):
     dx_p = ops.conv_dgrad(draw_p, wpk_t, Cin, k, s, (H, Wd), in_amax=est, in_presplit=True)
     assert torch.equal(dx_f, dx_p), "data gradient: pair staging differs from conversion while staging"
     dw_f, dw_p = torch.empty(Cout, Cin, k, k, device="cuda"), torch.empty(Cout, Cin, k, k, device="cuda")
-    ops.conv_wgrad(x, draw_f, dw_f, k, s, dy_amax=est, x_amax=x_amax)
-    ops.conv_wgrad(x, draw_p, dw_p, k, s, dy_amax=est, x_amax=x_amax, dy_presplit=True)
+    # (same kernel for both: the 16x16x32 form - csrc/conv_wgrad_wm16.hip - exists for pair tensors only and sums in another order)
+    old_wm16, ops.WM16 = ops.WM16, False
+    try:
+        ops.conv_wgrad(x, draw_f, dw_f, k, s, dy_amax=est, x_amax=x_amax)
+        ops.conv_wgrad(x, draw_p, dw_p, k, s, dy_amax=est, x_amax=x_amax, dy_presplit=True)
+    finally:
+        ops.WM16 = old_wm16
     assert torch.equal(dw_f, dw_p), "weight gradient: pair staging differs from conversion while staging"
+    ops.conv_wgrad(x, draw_p, dw_p, k, s, dy_amax=est, x_amax=x_amax, dy_presplit=True)      # the default pair path
+    assert float((dw_p - dw_f).abs().max()) <= 2e-6 * float(dw_f.abs().max()), "weight gradient: the default pair path"
     # ... and both are the gradients autograd gives for draw (fp64 yardstick)
     xc = x.cpu().permute(0, 3, 1, 2).double().requires_grad_(True)
     wc = w.cpu().double().requires_grad_(True)
@@ -159,8 +136,12 @@ def test_pair_tensor_paths_equal_the_fp32_draw_paths_bit_for_bit(ops, shape):
         assert torch.equal(sd_p.cpu().view(torch.int32), encode_pairs(sd_f.cpu(), sig).view(torch.int32))
         # the fused form and the separate pass compute the same draw up to the contraction of the fp32 expression
         assert float((sd_f - draw_f).abs().max()) <= 4e-6 * truth
-        ops.conv_wgrad(x, sd_p, dw_p, k, 1, dy_amax=est2, x_amax=x_amax, dy_presplit=True)
-        ops.conv_wgrad(x, sd_f, dw_f, k, 1, dy_amax=est2, x_amax=x_amax)
+        old_wm16, ops.WM16 = ops.WM16, False            # same kernel for both (the 16x16x32 form takes pair tensors only)
+        try:
+            ops.conv_wgrad(x, sd_p, dw_p, k, 1, dy_amax=est2, x_amax=x_amax, dy_presplit=True)
+            ops.conv_wgrad(x, sd_f, dw_f, k, 1, dy_amax=est2, x_amax=x_amax)
+        finally:
+            ops.WM16 = old_wm16
         assert torch.equal(dw_f, dw_p)
 
 

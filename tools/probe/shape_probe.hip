@@ -33,7 +33,11 @@ constexpr int PLANE4 = HALO * LP4;                           // one 16-channel p
 constexpr int CIN = 64;                                      // K = 9 taps x 64 channels = 576
 
 // ---- 32x32x16: unit = (tap, 16-channel plane); 3 x 2 accumulator tiles of 32 x 32 -------------------------------------
-template <int MT, int NT, int WPS>
+// ORDER: the issue order of the MT x NT x 3 products of a unit (per-accumulator order unchanged, so results are the same):
+//   0 = product-major, then row tile, then column tile (A repeats NT times, B alternates)      1 = accumulator-major: the three products of
+//   an accumulator back to back (a dependent chain, as conv_wgrad_wm_kernel issues them)      2 = product-major, column tile, row tile (B
+//   repeats MT times)      3 = row tile, product, column tile (one A fragment through all its uses before the next)
+template <int MT, int NT, int WPS, int ORDER = 0>
 __global__ __launch_bounds__(256, WPS) void loop32(const uint4* __restrict__ seed, const uint4* __restrict__ wpk, float* __restrict__ out,
                                               int iters) {
     extern __shared__ uint4 lds[];
@@ -69,16 +73,42 @@ __global__ __launch_bounds__(256, WPS) void loop32(const uint4* __restrict__ see
         for (int u = 0; u < UNITS; ++u) {
             const int cur = u & 1;
             if (u + 1 < UNITS) load(cur ^ 1, u + 1);
+            auto mm = [&](int sa, int sb, int i, int j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[cur][sa][i]), __builtin_bit_cast(f16x8, b[cur][sb][j]),
+                                                                  acc[i][j], 0, 0, 0);
+                if constexpr (ORDER >= 0) __builtin_amdgcn_sched_barrier(0);      // pin the issue order (the scheduler rotates accumulators by itself)
+            };
+            constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+            if constexpr (ORDER == 0) {
 #pragma unroll
-            for (int sa = 0; sa < 2; ++sa)
-#pragma unroll
-                for (int sb = 0; sb < 2 - sa; ++sb)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[cur][sa][i]),
-                                                                              __builtin_bit_cast(f16x8, b[cur][sb][j]), acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) mm(PA[p], PB[p], i, j);
+            } else if constexpr (ORDER == 1) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) mm(PA[p], PB[p], i, j);
+            } else if constexpr (ORDER == 2) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) mm(PA[p], PB[p], i, j);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) mm(PA[p], PB[p], i, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float s = 0.f;
@@ -196,6 +226,40 @@ static void run_config(const uint4* dseed, const uint4* dw, float* dout, size_t 
     CHECK(hipGetLastError());
 }
 
+template <int MT, int NT, int WPS, int ORDER>
+static void run_order(const uint4* dseed, const uint4* dw, float* dout, size_t lds_bytes) {
+    const int nblocks = 256 * 8, iters = 40;
+    auto k = loop32<MT, NT, WPS, ORDER>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const double flop = (double)nblocks * 4 * MT * 32 * NT * 32 * 9 * CIN * 2 * 3 * iters;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float ms = 0.f;
+    int reps = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int n = phase == 0 ? 600 : 100;
+        CHECK(hipEventRecord(e0));
+        for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k, dim3(nblocks), dim3(256), lds_bytes, 0, dseed, dw, dout, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        reps = n;
+    }
+    printf("  order %d  %.3f ms per launch  %.1f TFLOP/s of fp16 issue\n", ORDER, ms / reps, flop / (ms / reps * 1e-3) * 1e-12);
+    fflush(stdout);
+}
+template <int MT, int NT, int WPS>
+static void run_orders(const uint4* dseed, const uint4* dw, float* dout, size_t lds_bytes, const char* what) {
+    printf("%s\n", what);
+    for (int round = 0; round < 2; ++round) {
+        run_order<MT, NT, WPS, 0>(dseed, dw, dout, lds_bytes);
+        run_order<MT, NT, WPS, 1>(dseed, dw, dout, lds_bytes);
+        run_order<MT, NT, WPS, 2>(dseed, dw, dout, lds_bytes);
+        run_order<MT, NT, WPS, 3>(dseed, dw, dout, lds_bytes);
+    }
+}
+
 int main() {
     const size_t lds2 = (size_t)PLANE4 * 2 * 16;       // 75 KB: two blocks per CU, as conv_pipe_kernel
     // random fp16 operands: high terms uniform in (-1, 1), low terms 2^-11 of that (what split2h produces)
@@ -215,5 +279,9 @@ int main() {
     run_config<3, 2, 1>(dseed, dw, dout, 100 * 1024, "(a) one wave per SIMD");
     // (b) a 64 x 64 register tile, TWO waves per SIMD for both shapes
     run_config<2, 2, 2>(dseed, dw, dout, lds2, "(b) two waves per SIMD");
+    // (c) issue order of the products of a unit, 32x32x16, both tiles (round 4: does operand reuse between consecutive matrix instructions
+    //     change what the power envelope leaves?)
+    run_orders<3, 2, 1>(dseed, dw, dout, 100 * 1024, "(c) one wave per SIMD, 96 x 64");
+    run_orders<2, 2, 2>(dseed, dw, dout, lds2, "(c) two waves per SIMD, 64 x 64");
     return 0;
 }
