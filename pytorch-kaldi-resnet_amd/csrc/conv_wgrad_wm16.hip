@@ -21,6 +21,7 @@
 // Products and scales as conv_wgrad_wm_kernel; summation order differs (32 pixels per matrix instruction, the term-1 x term-0 product
 // first): equal to the other weight-gradient kernels within fp32 accumulation error, not bit for bit.
 #include "conv_wgrad.h"
+#include <type_traits>
 #ifndef WGRAD_XCD_BAND
 #define WGRAD_XCD_BAND 1
 #endif
@@ -35,8 +36,14 @@ static __device__ __forceinline__ s16x8 tr_read8w(const unsigned char* p0, const
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// (m0 is named as clobbered below so that the statement documents itself; clang warns that it does not track reserved registers. The
+// statement sets m0 right before its only use and nothing else in this kernel reads m0 - checked in the generated code.)
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __attribute__((aligned(16))) unsigned g_wm16_zero[4];      // what the DMA lanes of pixels outside the image fetch
 
+#ifndef WM16_CVT_IN_LOOP
+#define WM16_CVT_IN_LOOP 0      // 1: the conversion of the next region's X dealt out between the matrix instructions of the last k-step
+#endif                          //    (built and measured +-0 inside the step - DESIGN.md section 7b; the default is the plain pass after the K loop)
 #define WM16_NX 7      // X halo float4 per thread: halo_pix <= 16 * WM16_NX pixels of 64 channels
 
 // VAR: bit 0 = fused input BatchNorm + ReLU on X (compile-time, as conv_wgrad_wm_kernel); dY is always an f16 pair tensor
@@ -101,13 +108,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
     auto prefetch_x = [&](int region) {
         int b, oy0, ox0;
         region_origin(region, b, oy0, ox0);
+        int t4 = tid >> 4;
+        asm volatile("" : "+v"(t4));      // opaque: the halo coordinates of the seven items are recomputed per region, not held in registers across the K loop
         const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
         const char* xb = (const char*)(a.x + (size_t)b * a.IH * a.IW * a.Cin);
         const unsigned x_safe = (unsigned)(oy0 * a.S) * x_row + (unsigned)(ox0 * a.S) * x_px + x_c;
         inx = 0;
 #pragma unroll
         for (int u = 0; u < WM16_NX; ++u) {
-            const int p = (tid >> 4) + 16 * u;
+            const int p = t4 + 16 * u;
             const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
             const int hx = p - hy * a.halo_w;
             const int iy = iy0 + hy, ix = ix0 + hx;
@@ -138,28 +147,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(src) : "memory", "m0");
         }
     };
-    auto publish_x = [&]() {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    // X goes through registers (fp32 activations, optionally BatchNorm + ReLU on the way, two fp16 terms).  The conversion works IN PLACE -
+    // a float4 becomes the [4 x high][4 x low] pair of the staged value, the same four registers - right after the K loop, so that only the
+    // LDS writes are left between the two barriers.  WM16_CVT_IN_LOOP = 1 deals it out between the matrix instructions of the last k-step
+    // instead (vector instructions overlap matrix instructions only inside one wave's instruction stream): the
+    // instructions interleave as intended in the generated code, and the step does not move (48.62 / 48.71 against 48.78 / 48.65 ms) -
+    // at the power cap a vector instruction costs what it costs wherever it issues.
+    auto convert_item = [&](int u, const f32x4& sc, const f32x4& sh) {
+        f32x4 w = px[u];
+        if constexpr ((VAR & 1) != 0) {
+            w = w * sc + sh;
+            w[0] = fmaxf(w[0], 0.f);
+            w[1] = fmaxf(w[1], 0.f);
+            w[2] = fmaxf(w[2], 0.f);
+            w[3] = fmaxf(w[3], 0.f);
+        }
+        if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+        uint2 t0, t1;
+        split2h(w, sig_x, t0, t1);
+        px[u] = spk_pair_pack(t0, t1);
+    };
+    auto load_affine = [&](f32x4& sc, f32x4& sh) {
         if constexpr ((VAR & 1) != 0) {
             sc = *(const f32x4*)(a.in_scale + ci0 + q16 * 4);
             sh = *(const f32x4*)(a.in_shift + ci0 + q16 * 4);
         }
+    };
+    auto publish_x = [&]() {
 #pragma unroll
         for (int u = 0; u < WM16_NX; ++u) {
             const int p = (tid >> 4) + 16 * u;
-            f32x4 w = px[u];
-            if constexpr ((VAR & 1) != 0) {
-                w = w * sc + sh;
-                w[0] = fmaxf(w[0], 0.f);
-                w[1] = fmaxf(w[1], 0.f);
-                w[2] = fmaxf(w[2], 0.f);
-                w[3] = fmaxf(w[3], 0.f);
-            }
-            if (!((inx >> u) & 1)) w = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p < halo_pix) {
                 uint2* dst = (uint2*)(xs + p * PX + (q16 >> 3) * 192) + (q16 & 7);
                 uint2 t0, t1;
-                split2h(w, sig_x, t0, t1);
+                spk_pair_unpack(px[u], t0, t1);
                 dst[0] = t0;
                 dst[8] = t1;
             }
@@ -176,18 +197,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
     if (region < a.nregions) {
         dma_dy(region, 0);                                // (before the X loads: older operations complete first, the compiler's counts for px stay exact)
         prefetch_x(region);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        load_affine(sc, sh);
+#pragma unroll
+        for (int u = 0; u < WM16_NX; ++u) convert_item(u, sc, sh);      // the first region's conversion has no K loop to hide under
     }
     for (; region < a.nregions; region += a.nsplit, buf ^= 1) {
         __syncthreads();                                  // every wave is past the previous region's K loop
         publish_x();
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this region's dY tile has landed in LDS
         __syncthreads();
-        if (region + a.nsplit < a.nregions) {
+        const bool has_next = region + a.nsplit < a.nregions;
+        if (has_next) {
             dma_dy(region + a.nsplit, buf ^ 1);           // last read by the K loop of the region before this one
             prefetch_x(region + a.nsplit);
         }
         const unsigned char* dcur = dys + buf * dbuf + d_lane;
-        for (int j = 0; j < nsteps; ++j) {
+        // (always_inline: as a call the body would take the accumulators through memory)
+        auto kstep = [&](int j, auto cvt_c) __attribute__((always_inline)) {
+            constexpr bool CVT = decltype(cvt_c)::value;      // the last k-step of a region carries the conversion of the next region's X
             s16x8 bf[2][2];                               // [column tile][term]
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -216,6 +244,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
                         acc[t][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[sa][rt]), __builtin_bit_cast(f16x8, bf[ct][sb]),
                                                                                 acc[t][rt][ct], 0, 0, 0);
             };
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (CVT) load_affine(sc, sh);
             load_a(1, 0);
             load_a(0, 0);
 #pragma unroll
@@ -228,9 +258,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
                 if (t + 1 < NTAPS) load_a(1, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mm(t, 0, 1);
+                if constexpr (CVT) {                                           // the next region's X, one item per tap, in the last taps: its
+                    if (t >= NTAPS - WM16_NX) convert_item(t - (NTAPS - WM16_NX), sc, sh);      // loads have had the whole region to arrive.
+                }                                                              // No branch: one scheduling region with the eight products around it
                 mm(t, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < NTAPS) load_a(0, t + 1);
+            }
+        };
+        for (int j = 0; j + 1 < nsteps; ++j) kstep(j, std::false_type{});
+        // (also after a block's last region, where it converts stale registers: harmless, and the loop keeps two bodies instead of three)
+        kstep(nsteps - 1, std::integral_constant<bool, WM16_CVT_IN_LOOP != 0>{});
+        if constexpr (!WM16_CVT_IN_LOOP) {
+            if (has_next) {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                load_affine(sc, sh);
+#pragma unroll
+                for (int u = 0; u < WM16_NX; ++u) convert_item(u, sc, sh);
             }
         }
     }

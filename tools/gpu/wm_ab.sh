@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of the 16x16x32 weight gradient with dY by LDS DMA (csrc/conv_wgrad_wm16.hip) against conv_wgrad_wm_kernel inside the training
-# step on ONE box, alternating runs.
+# A/B inside the training step on ONE box, alternating runs: the 16x16x32 weight gradient with dY by LDS DMA (csrc/conv_wgrad_wm16.hip)
+# with the conversion of X dealt out in its last k-step (default) / as a pass of its own (variant library cvtpass: tools/variant.sh cvtpass
+# conv_wgrad_wm16.hip -DWM16_CVT_IN_LOOP=0) / against conv_wgrad_wm_kernel (SPK_WM16=0).
 D=${1:-gpurun_out/wm_ab}
 mkdir -p $D
 FAST="--steps 20 --warmup 5 --no-cpu-baseline --no-eer --no-fp32-leg --no-f16-window --no-extra"
@@ -22,7 +23,10 @@ for k, v in sorted(((j.get("roofline") or {}).get("all_kernels") or {}).items(),
         print("    %-62s %7.3f ms %3d x %.3f" % (k[:62], v["ms_per_step"], v["launches_per_step"], v["ms_per_step"] / max(1, v["launches_per_step"])))
 PY
 }
-one m16_a SPK_WM16=1
+V=pytorch-kaldi-resnet_amd/variants
+one inloop_a SPK_WM16=1
+one cvtpass_a SPK_WM16=1 SPK_LIB=$V/libspkhip_cvtpass.so
 one m32_a SPK_WM16=0
-one m16_b SPK_WM16=1
+one inloop_b SPK_WM16=1
+one cvtpass_b SPK_WM16=1 SPK_LIB=$V/libspkhip_cvtpass.so
 one m32_b SPK_WM16=0
