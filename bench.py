@@ -62,7 +62,7 @@ def mfma_peak(kernel_label):
         terms = int(inner[4])
     elif kernel_label.startswith("conv_wgrad_split_kernel") and len(inner) == 5:
         terms = int(inner[3])
-    elif kernel_label.startswith(("conv_pipe_kernel", "conv_wgrad_wm_kernel", "conv_wgrad_wm16_kernel", "conv_wgrad_1x1_kernel", "conv_wgrad_pipe_kernel",
+    elif kernel_label.startswith(("conv_pipe_kernel", "conv_wgrad_wm_kernel", "conv_wgrad_wm16_kernel", "conv_wgrad_c32m16_kernel", "conv_wgrad_1x1_kernel", "conv_wgrad_pipe_kernel",
                                   "conv_wgrad_ws_kernel")):
         terms = 3           # these forms exist for the f16x3 operand mode only
     if terms:

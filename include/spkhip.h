@@ -70,7 +70,11 @@ int spk_build_flags(void);
 #define SPK_WGRAD_M16 (1 << 19) /* spk_conv_wgrad + SPK_WGRAD_GROUPS, 3x3, with SPK_DY_PRESPLIT: conv_wgrad_wm16_kernel - the 2 x 2 wave layout on
                                 v_mfma_f32_16x16x32_f16 (32 pixels per K step), dy brought into LDS by global_load_lds (no registers, no
                                 staging instructions; two LDS buffers).  LDS: halo * 384 + 2 * ceil32(TH * TW) * 256 bytes.  Same products,
-                                another summation order: equal to the other weight gradients within fp32 accumulation error */
+                                another summation order: equal to the other weight gradients within fp32 accumulation error.
+                                WITHOUT SPK_WGRAD_GROUPS (3x3, WN = 1, SPK_DY_PRESPLIT): conv_wgrad_c32m16_kernel - the same kernel in its
+                                layout for 32-channel groups (the first layer): a block owns 32 x 32 channels, its four waves split the
+                                32-pixel k-steps of a region and fold their tiles through LDS at the end; halo <= 192 pixels, LDS: halo *
+                                192 + 2 * ceil32(TH * TW) * 128 bytes (at least 36 KB); one slab per block as every other form */
 #define SPK_IN_PRESPLIT (1 << 14)    /* spk_conv_mfma: `in` is an f16 pair tensor scaled by the sigma of *in_amax (plain input only) */
 #define SPK_SIDE_PRESPLIT (1 << 15)  /* spk_conv_mfma + SPK_IN_BNBWD: side_draw leaves as an f16 pair tensor (scale: *in_amax) */
 #define SPK_DY_PRESPLIT (1 << 16)    /* spk_conv_wgrad: `dy` is an f16 pair tensor scaled by the sigma of *dy_amax */

@@ -19,6 +19,7 @@ int spk_launch_wgrad_ws(const WgradArgs& a, int WN, hipStream_t st);
 int spk_launch_wgrad_pipe(const WgradArgs& a, int WN, hipStream_t st);
 int spk_launch_wgrad_1x1(const WgradArgs& a, int WN, int CG, hipStream_t st);
 int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st);                 // conv_wgrad_wm16.hip: the same on 16x16x32, dy by LDS DMA
+int spk_launch_wgrad_c32m16(const WgradArgs& a, hipStream_t st);               //   ... and its layout for 32-channel groups (four slabs per block)
 int spk_launch_wgrad_wm(const WgradArgs& a, hipStream_t st);                   // conv_wgrad_wm.hip: 2 x 2 wave layout (3x3)   // conv_wgrad_1x1.hip: input-channel groups as "taps"      // conv_wgrad_pipe.hip: in-wave pipelined form        // conv_wgrad_split.hip: producer / consumer form
 
 template <int NTAPS, int WK, int WN>
@@ -309,6 +310,11 @@ extern "C" int spk_conv_wgrad(const float* x, const float* dy, float* dw, float*
     SPK_REQUIRE(split != 3 || (dy_amax && x_amax), "spk_conv_wgrad: the f16x3 operand mode needs dy_amax and x_amax (slots with the float bits of the operands' absmax or of upper bounds)");
     SPK_REQUIRE(!(flags & SPK_DY_PRESPLIT) || (split == 3 && !(flags & (SPK_CONV_PIPE | SPK_CONV_WS))),
                 "spk_conv_wgrad: DY_PRESPLIT (dy as an f16 pair tensor) needs the f16x3 mode (not the opt-in pipelined / wave-specialised forms)");
+    if ((flags & SPK_WGRAD_M16) && !(flags & SPK_WGRAD_GROUPS)) {      // 32-channel groups on 16x16x32, dy by LDS DMA
+        SPK_REQUIRE(split == 3 && ksize == 3 && WN == 1, "spk_conv_wgrad: SPK_WGRAD_M16 without SPK_WGRAD_GROUPS is the 32-channel-group 3x3 kernel (f16x3, WN = 1)");
+        a.flags = flags & (SPK_IN_AFFINE_RELU | SPK_DY_PRESPLIT);
+        return spk_launch_wgrad_c32m16(a, (hipStream_t)stream);
+    }
     if (flags & SPK_WGRAD_GROUPS) {       // f16x3: bits 12-13 of flags = log2 of the input-channel groups per block
         SPK_REQUIRE(split == 3, "spk_conv_wgrad: the grouped kernels exist in the f16x3 mode");
         const int cg = 1 << ((flags >> 12) & 3);

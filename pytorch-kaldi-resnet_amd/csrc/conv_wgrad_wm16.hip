@@ -44,20 +44,29 @@ __device__ __attribute__((aligned(16))) unsigned g_wm16_zero[4];      // what th
 #ifndef WM16_CVT_IN_LOOP
 #define WM16_CVT_IN_LOOP 0      // 1: the conversion of the next region's X dealt out between the matrix instructions of the last k-step
 #endif                          //    (built and measured +-0 inside the step - DESIGN.md section 7b; the default is the plain pass after the K loop)
-#define WM16_NX 7      // X halo float4 per thread: halo_pix <= 16 * WM16_NX pixels of 64 channels
-
-// VAR: bit 0 = fused input BatchNorm + ReLU on X (compile-time, as conv_wgrad_wm_kernel); dY is always an f16 pair tensor
-template <int VAR>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
+// VAR: bit 0 = fused input BatchNorm + ReLU on X (compile-time, as conv_wgrad_wm_kernel); dY is always an f16 pair tensor.
+// C32: the layout for 32-channel groups (the first layer: Cin = Cout = 32).  A block owns 32 x 32 channels, every wave holds the whole
+// 9 x 32 x 32 tile and the four waves split the k-steps of a region (wave w takes steps w, w + 4, ...); at the end of the block the four
+// tiles are folded through LDS in a fixed order (a first version wrote four slabs per block and left the fold to the slab reduce: 2 048
+// slabs made that kernel - 36 blocks, a serial walk over the slabs - 0.14 ms instead of 0.02).  X pixels are 128 bytes (8 threads, 32
+// pixels per staging pass), a DMA chunk is 8 pixels x 8 channel groups: piece (pixel p8, group c) in slot (p8 >> 2) * 32 + (c >> 2) * 16 +
+// (c & 3) * 4 + (p8 & 3) - again sixteen different 16-byte slots of a 256-byte row for the sixteen lanes of a transposed read.
+template <int VAR, bool C32>
+static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int NTAPS = 9, KS = 3;
-    constexpr int PX = 2 * 192;                           // X bytes per staged pixel: [2 groups][3-term pitch][32 ch fp16]
+    constexpr int CGL = C32 ? 5 : 6;                      // log2 of the channels per block side
+    constexpr int PX = C32 ? 192 : 2 * 192;               // X bytes per staged pixel: [1 or 2 groups][3-term pitch][32 ch fp16]
+    constexpr int QXL = C32 ? 3 : 4;                      // log2 of the threads (float4) per X pixel
+    constexpr int PXP = 256 >> QXL;                       // X pixels per staging pass
+    constexpr int WM16_NX = C32 ? 6 : 7;                  // X halo float4 per thread: halo_pix <= PXP * WM16_NX (192 / 112 pixels)
+    constexpr int CPL = C32 ? 3 : 2;                      // log2 of the pixels per DMA chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = C32 ? 0 : wave >> 1, wn = C32 ? 0 : wave & 1;
     int g, ci0, co0;                                      // block -> (region slice, channel groups): conv_wgrad_split.hip, wgrad_block
     {
-        const int ncgi = a.Cin >> 6, M = ncgi * (a.Cout >> 6);
+        const int ncgi = a.Cin >> CGL, M = ncgi * (a.Cout >> CGL);
         const int bid = blockIdx.x;
         int m;
         if ((a.nsplit & 7) == 0) {
@@ -68,13 +77,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
             m = bid % M;
             g = bid / M;
         }
-        ci0 = (m % ncgi) * 64;
-        co0 = (m / ncgi) * 64;
+        ci0 = (m % ncgi) << CGL;
+        co0 = (m / ncgi) << CGL;
     }
     const int halo_pix = a.halo_h * a.halo_w;
     const int npix = a.TH * a.TW;
     const int nsteps = (npix + 31) >> 5;                  // k-steps of 32 pixels; the padding pixels of dY are zero
-    const int nchunks = nsteps << 3;                      // 4-pixel chunks of a dY buffer
+    const int nchunks = nsteps << (5 - CPL);              // DMA chunks (1024 bytes: 4 pixels x 64 channels or 8 x 32) of a dY buffer
     unsigned char* xs = ldsb;
     unsigned char* dys = ldsb + halo_pix * PX;            // two buffers of nchunks * 1024 bytes
     const int dbuf = nchunks << 10;
@@ -89,13 +98,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int q16 = tid & 15;                             // this thread's float4 of the 64 channels of an X pixel
+    const int q16 = tid & ((1 << QXL) - 1);               // this thread's float4 of the 64 (32) channels of an X pixel
     f32x4 px[WM16_NX];
     unsigned inx = 0;
     const unsigned x_row = (unsigned)a.IW * a.Cin * 4u, x_px = (unsigned)a.Cin * 4u;
     const unsigned d_row = (unsigned)a.OW * a.Cout * 4u, d_px = (unsigned)a.Cout * 4u;
     const unsigned x_c = (unsigned)(ci0 + q16 * 4) * 4u;
-    const unsigned d_c = (unsigned)(co0 + ((((lane >> 4) << 2) | ((lane >> 2) & 3)) << 2)) * 4u;     // the DMA lane's channel group
+    const unsigned d_c = (unsigned)(co0 + (((((lane >> 4) & (C32 ? 1 : 3)) << 2) | ((lane >> 2) & 3)) << 2)) * 4u;     // the DMA lane's channel group
+    const int d_pl = C32 ? ((lane >> 5) << 2) | (lane & 3) : lane & 3;                                              // ... and pixel of the chunk
     auto region_origin = [&](int region, int& b, int& oy0, int& ox0) {
         int pt = region;
         const int tx = pt % a.tiles_x;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
     auto prefetch_x = [&](int region) {
         int b, oy0, ox0;
         region_origin(region, b, oy0, ox0);
-        int t4 = tid >> 4;
+        int t4 = tid >> QXL;
         asm volatile("" : "+v"(t4));      // opaque: the halo coordinates of the seven items are recomputed per region, not held in registers across the K loop
         const int iy0 = oy0 * a.S - a.pad, ix0 = ox0 * a.S - a.pad;
         const char* xb = (const char*)(a.x + (size_t)b * a.IH * a.IW * a.Cin);
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
         inx = 0;
 #pragma unroll
         for (int u = 0; u < WM16_NX; ++u) {
-            const int p = t4 + 16 * u;
+            const int p = t4 + PXP * u;
             const int hy = (int)__umulhi((unsigned)p, a.halo_w_magic);
             const int hx = p - hy * a.halo_w;
             const int iy = iy0 + hy, ix = ix0 + hx;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
         const char* db = (const char*)(a.dy + (size_t)b * a.OH * a.OW * a.Cout);
         unsigned char* dst = dys + buf * dbuf;
         for (int ch = wave; ch < nchunks; ch += 4) {
-            const int p = 4 * ch + (lane & 3);
+            const int p = (ch << CPL) + d_pl;
             const int ly = (int)__umulhi((unsigned)p, a.tw_magic);
             const int lx = p - ly * a.TW;
             const int oy = oy0 + ly, ox = ox0 + lx;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
     auto publish_x = [&]() {
 #pragma unroll
         for (int u = 0; u < WM16_NX; ++u) {
-            const int p = (tid >> 4) + 16 * u;
+            const int p = (tid >> QXL) + PXP * u;
             if (p < halo_pix) {
                 uint2* dst = (uint2*)(xs + p * PX + (q16 >> 3) * 192) + (q16 & 7);
                 uint2 t0, t1;
@@ -191,7 +201,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
     // One transposed read hands a lane 4 pixels of its channel from the 16 lanes (pixel q, 4-channel piece p4) of its group.
     const int kg = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
     const int a_lane = wm * 192 + p4 * 8;                                  // X: [group wm][term][32 ch]: row tile rt at + 32 rt, term s at + 64 s
-    const int d_lane = (2 * kg) * 1024 + wn * 512 + p4 * 64 + q * 16;      // dY: chunk 2 kg (+ 1), slot (2 wn + ct) * 16 + 4 p4 + q, term s at + 8 s
+    // dY: pixels 8 kg + 4 blk + q of the step: chunk 2 kg + blk, slot (2 wn + ct) * 16 + 4 p4 + q (C32: chunk kg, slot 32 blk + 16 ct + 4 p4 + q); term s at + 8 s
+    const int d_lane = (C32 ? kg : 2 * kg) * 1024 + wn * 512 + p4 * 64 + q * 16;
+    constexpr int D_STEP = C32 ? 4096 : 8192, D_BLK = C32 ? 512 : 1024;
 
     int region = g, buf = 0;
     if (region < a.nregions) {
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) bf[ct][s] = tr_read8w(dcur + (j << 13) + ct * 256 + s * 8, dcur + (j << 13) + 1024 + ct * 256 + s * 8);
+                for (int s = 0; s < 2; ++s) bf[ct][s] = tr_read8w(dcur + j * D_STEP + ct * 256 + s * 8, dcur + j * D_STEP + D_BLK + ct * 256 + s * 8);
             int xa[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -266,10 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
                 if (t + 1 < NTAPS) load_a(0, t + 1);
             }
         };
-        for (int j = 0; j + 1 < nsteps; ++j) kstep(j, std::false_type{});
-        // (also after a block's last region, where it converts stale registers: harmless, and the loop keeps two bodies instead of three)
-        kstep(nsteps - 1, std::integral_constant<bool, WM16_CVT_IN_LOOP != 0>{});
-        if constexpr (!WM16_CVT_IN_LOOP) {
+        if constexpr (C32) {
+            for (int j = wave; j < nsteps; j += 4) kstep(j, std::false_type{});       // the four waves split the k-steps
+        } else {
+            for (int j = 0; j + 1 < nsteps; ++j) kstep(j, std::false_type{});
+            // (also after a block's last region, where it converts stale registers: harmless, and the loop keeps two bodies instead of three)
+            kstep(nsteps - 1, std::integral_constant<bool, WM16_CVT_IN_LOOP != 0>{});
+        }
+        if constexpr (C32 || !WM16_CVT_IN_LOOP) {
             if (has_next) {
                 f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
                 load_affine(sc, sh);
@@ -279,6 +295,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
         }
     }
 
+    if constexpr (C32) {
+        // fold the four waves' tiles (each a partial sum over its k-steps) through LDS in a fixed order: waves 1-3 write three taps at a
+        // time (12 float4 per lane, 36 KB), wave 0 adds them - w1, w2, w3 - and writes the block's one slab
+        f32x4* red = (f32x4*)ldsb;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            __syncthreads();                              // (first round: every wave is past its last K loop)
+            if (wave > 0) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) red[((wave - 1) * 12 + i) * 64 + lane] = acc[3 * tt + i / 4][(i >> 1) & 1][i & 1];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc[3 * tt + i / 4][(i >> 1) & 1][i & 1] += red[(w * 12 + i) * 64 + lane];
+            }
+        }
+        if (wave != 0) return;
+    }
     float* slab = a.partial + (size_t)g * NTAPS * a.Cin * a.Cout;
     const float inv = (1.f / sig_x) * (1.f / sig_d);
 #pragma unroll
@@ -294,20 +331,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) {
                 }
 }
 
-size_t spk_wgrad_wm16_lds_bytes(int halo_pix, int npix) { return (size_t)halo_pix * 384 + 2 * (size_t)(((npix + 31) >> 5) << 5) * 256; }
+// (two kernel names, one body: profiles and labels tell the layouts apart)
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wm16_kernel(WgradArgs a) { wgrad_m16_body<VAR, false>(a); }
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c32m16_kernel(WgradArgs a) { wgrad_m16_body<VAR, true>(a); }
 
 int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st) {
     SPK_REQUIRE(a.KW == 3 && a.Cin % 64 == 0 && a.Cout % 64 == 0, "spk_conv_wgrad(2x2 waves, 16x16x32): 3x3, Cin and Cout multiples of 64 (%d, %d)", a.Cin, a.Cout);
     SPK_REQUIRE(a.flags & SPK_DY_PRESPLIT, "spk_conv_wgrad(2x2 waves, 16x16x32): dy must be an f16 pair tensor (SPK_DY_PRESPLIT): it is staged by the DMA path");
-    SPK_REQUIRE(a.halo_h * a.halo_w <= 16 * WM16_NX, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d (halo %dx%d) exceeds the prefetch window", a.TH, a.TW,
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 16 * 7, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d (halo %dx%d) exceeds the prefetch window", a.TH, a.TW,
                 a.halo_h, a.halo_w);
     SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
                 "spk_conv_wgrad(2x2 waves, 16x16x32): an image exceeds 32-bit byte offsets");
-    const size_t lds_bytes = spk_wgrad_wm16_lds_bytes(a.halo_h * a.halo_w, a.TH * a.TW);
+    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 384 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 256;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
     if (a.flags & SPK_IN_AFFINE_RELU) hipLaunchKernelGGL(conv_wgrad_wm16_kernel<1>, grid, dim3(256), lds_bytes, st, a);
     else hipLaunchKernelGGL(conv_wgrad_wm16_kernel<0>, grid, dim3(256), lds_bytes, st, a);
     SPK_LAUNCH_CHECK("spk_conv_wgrad(2x2 waves, 16x16x32)");
+    return 0;
+}
+
+// the 32-channel-group layout
+int spk_launch_wgrad_c32m16(const WgradArgs& a, hipStream_t st) {
+    SPK_REQUIRE(a.KW == 3 && a.Cin % 32 == 0 && a.Cout % 32 == 0, "spk_conv_wgrad(32-channel groups, 16x16x32): 3x3, channels multiples of 32 (%d, %d)", a.Cin, a.Cout);
+    SPK_REQUIRE(a.flags & SPK_DY_PRESPLIT, "spk_conv_wgrad(32-channel groups, 16x16x32): dy must be an f16 pair tensor (SPK_DY_PRESPLIT): it is staged by the DMA path");
+    SPK_REQUIRE(a.halo_h * a.halo_w <= 32 * 6, "spk_conv_wgrad(32-channel groups, 16x16x32): tile %dx%d (halo %dx%d) exceeds the prefetch window", a.TH, a.TW,
+                a.halo_h, a.halo_w);
+    SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
+                "spk_conv_wgrad(32-channel groups, 16x16x32): an image exceeds 32-bit byte offsets");
+    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 192 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 128;
+    if (lds_bytes < 3 * 12 * 64 * 16) lds_bytes = 3 * 12 * 64 * 16;      // the fold of the four waves' tiles at the end of a block
+    SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(32-channel groups, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
+    dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / 32));
+    if (a.flags & SPK_IN_AFFINE_RELU) hipLaunchKernelGGL(conv_wgrad_c32m16_kernel<1>, grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_c32m16_kernel<0>, grid, dim3(256), lds_bytes, st, a);
+    SPK_LAUNCH_CHECK("spk_conv_wgrad(32-channel groups, 16x16x32)");
     return 0;
 }

@@ -160,6 +160,7 @@ PIPE_WGRAD = os.environ.get("SPK_WGRAD_PIPE", "0") == "1"
 PIPE_BNBWD = os.environ.get("SPK_PIPE_BNBWD", "0") == "1"
 GROUPED_1X1 = os.environ.get("SPK_WGRAD_1X1_GROUPS", "1") == "1"   # 1x1 weight gradients: input-channel groups as "taps"
 WM16 = os.environ.get("SPK_WM16", "1") == "1"             # 3x3 grouped weight gradient with a pair-tensor dy: 16x16x32 form, dy by LDS DMA (csrc/conv_wgrad_wm16.hip)
+C32M16 = os.environ.get("SPK_C32M16", "1") == "1"         # ... and its 32-channel-group layout for the first layer's weight gradients
 WM_SHIFT = os.environ.get("SPK_WM_SHIFT", "1") == "1"      # 3x3 grouped weight gradient: shifted-window K loop where it applies (csrc/conv_wgrad_wm.hip, SH)
 GROUPED_3X3 = os.environ.get("SPK_WGRAD_3X3_GROUPS", "1") == "1"   # 3x3 weight gradients: 2 x 2 (cin group x cout group) wave layout
 GROUPED_1X1_BLOCKS = int(os.environ.get("SPK_WGRAD_1X1_BLOCKS", "512"))
@@ -627,6 +628,8 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
         tiling.FORCE_WGRAD[wkey] = tiling._wgrad_tile(*wkey)      # placeholder: stops the recursion below
         _autotune_wgrad(wkey, x, dy, ksize, stride, in_affine, dy_amax, x_amax, dy_presplit)
     TH, TW, WN = tiling.wgrad_tile(OH, OW, Cin, Cout, ksize, stride, split=split)
+    if C32M16 and split == 3 and ksize == 3 and WN == 1 and dy_presplit:
+        TH, TW, WN = tiling.c32m16_tile(OH, OW, Cin, Cout, ksize, stride) or (TH, TW, WN)      # the 32-channel-group 16x16x32 kernel has its own tile rule
     nreg = B * (-(-OH // TH)) * (-(-OW // TW))
     # producer / consumer kernel (csrc/conv_wgrad_split.hip: conv_wgrad_ws_kernel): f16x3 3x3 launches whose two LDS slots fit
     halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
@@ -646,11 +649,15 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     wm = (GROUPED_3X3 and not wgws and not wgp and split == 3 and ksize == 3 and WN == 2 and Cin % 64 == 0 and Cout % 64 == 0
           and halo <= 112 and TH * TW <= 64 and halo * 384 + -(-(TH * TW) // 16) * 16 * 448 <= 80 * 1024)
     wm16 = wm and WM16 and dy_presplit and halo * 384 + 2 * -(-(TH * TW) // 32) * 32 * 256 <= 80 * 1024
+    # ... and the same kernel in its 32-channel-group layout (the first layer): four waves split the k-steps and fold at the end of the block
+    c32m16 = (C32M16 and not wm and not wgws and not wgp and split == 3 and ksize == 3 and WN == 1 and dy_presplit and halo <= 192
+              and halo * 192 + 2 * -(-(TH * TW) // 32) * 32 * 128 <= 80 * 1024)
     if wm:
         cg = 2
     nsplit = min(nreg, tiling.wgrad_nsplit(nreg, Cin, Cout, WN, WS_WGRAD_BLOCKS if wgws else (GROUPED_1X1_BLOCKS if cg else None),
                                            cin_groups=cg or 1))
-    nbytes = hip.lib().spk_conv_wgrad_workspace(nsplit, ksize, Cin, Cout)
+    nslab = nsplit
+    nbytes = hip.lib().spk_conv_wgrad_workspace(nslab, ksize, Cin, Cout)
     ws = _workspace(nbytes, x.device)
     flags = (IN_AFFINE_RELU if in_affine is not None else 0) | (CONV_WS if wgws else 0) | (CONV_PIPE if wgp else 0)
     if cg:
@@ -659,13 +666,13 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
         flags |= DY_PRESPLIT
     if wm and not WM_SHIFT:
         flags |= hip.WGRAD_NOSHIFT
-    if wm16:
+    if wm16 or c32m16:
         flags |= hip.WGRAD_M16
     call("spk_conv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws),
          ptr(in_affine[0]) if in_affine else None, ptr(in_affine[1]) if in_affine else None,
          B, IH, IW, Cin, OH, OW, Cout, ksize, stride, TH, TW, WN, nsplit, flags, 1 if accumulate else 0, split,
          ptr(dy_amax) if split == 3 else None, ptr(x_amax) if split == 3 else None, stream(),
-         label=("conv_wgrad_wm16_kernel" if wm16 else "conv_wgrad_wm_kernel" if wm
+         label=("conv_wgrad_wm16_kernel" if wm16 else "conv_wgrad_c32m16_kernel" if c32m16 else "conv_wgrad_wm_kernel" if wm
          else ("conv_wgrad_1x1_kernel<%d,%d,%d>" % (4 // WN, WN, cg)) if cg
          else ("conv_wgrad_ws_kernel<%d,%d,%d,%d>" % (ksize * ksize, 4 // WN, WN, 4 if halo <= 128 else 5)) if wgws
          else ("conv_wgrad_pipe_kernel<%d,%d,%d,%d>" % (4 // WN, WN, 4 if halo <= 128 else 5, nst // (4 // WN))) if wgp
@@ -674,7 +681,7 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
          else "conv_wgrad_kernel<%d,%d,%d>" % (ksize * ksize, 4 // WN, WN)) + (
              " C%d %dx%d" % (Cout, OH, OW) if LABEL_SHAPES else ""),
          flops=2.0 * B * OH * OW * Cout * Cin * ksize * ksize, nbytes=4.0 * (x.numel() + dy.numel() + nbytes / 4))
-    call("spk_wgrad_reduce", ptr(ws), ptr(dw), nsplit, ksize, Cin, Cout, 1 if accumulate else 0, stream())
+    call("spk_wgrad_reduce", ptr(ws), ptr(dw), nslab, ksize, Cin, Cout, 1 if accumulate else 0, stream())
     return dw
 
 

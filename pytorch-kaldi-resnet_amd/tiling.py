@@ -25,6 +25,7 @@ FORCE_CONV = {}
 FORCE_CONV_SPLIT = {}     # the same launch shapes in the bf16-split operand mode (112 B of LDS per pixel, faster MFMA phase)
 FORCE_WGRAD = {}
 FORCE_CONV_WS = {}        # wave-specialised kernel (csrc/conv_ws_kernel.h): key -> (TH, TW, MT, NT, WC)
+FORCE_WGRAD_C32M16 = {}   # tiles of the 32-channel-group 16x16x32 weight gradient (tests / sweeps; default: wgrad_tile_c32m16's rule)
 FORCE_WGRAD_SPLIT = {}    # weight-gradient tiles of the bf16-split kernel (K = 16 pixels per MFMA: tiles of 16 k pixels pad least)
 
 
@@ -242,6 +243,39 @@ def _conv_tile(OH, OW, IS, kspan_y, kspan_x, ntaps, Cout):
                     best = (key, (TH, TW, MT, NT))
     assert best is not None, "no conv tile for %dx%d" % (OH, OW)
     return best[1]
+
+
+def c32m16_tile(OH, OW, Cin, Cout, ksize, stride):
+    """tile of conv_wgrad_wm16_kernel<., C32> for a shape: SPK_WGRAD_TILE override, then FORCE_WGRAD_C32M16, then the rule below"""
+    key = (OH, OW, Cin, Cout, ksize, stride)
+    if key in _WGRAD_TILE_OVERRIDE:
+        return _WGRAD_TILE_OVERRIDE[key]
+    if key in FORCE_WGRAD_C32M16:
+        return FORCE_WGRAD_C32M16[key]
+    return wgrad_tile_c32m16(OH, OW, ksize, stride)
+
+
+@lru_cache(maxsize=None)
+def wgrad_tile_c32m16(OH, OW, ksize, stride):
+    """Tile (TH, TW, WN = 1) for conv_wgrad_wm16_kernel<., C32> (csrc/conv_wgrad_wm16.hip): k-steps of 32 pixels dealt to four waves, so a
+    region costs ceil(steps / 4) step times; halo <= 192 pixels (six 32-pixel staging passes); X 192 B and two dY buffers of 128 B per
+    pixel within 80 KB (two blocks per CU).  Ties go to the wider tile (longer contiguous runs for the DMA chunks of 8 pixels)."""
+    best = None
+    for TH in range(1, OH + 1):
+        for TW in range(2, OW + 2, 2):
+            npix = TH * TW
+            if npix > 256:
+                break
+            halo = ((TH - 1) * stride + ksize) * ((TW - 1) * stride + ksize)
+            steps = -(-npix // 32)
+            if halo > 192 or halo * 192 + 2 * steps * 32 * 128 > 80 * 1024:
+                continue
+            ty, tx = -(-OH // TH), -(-OW // TW)
+            cost = ty * tx * (-(-steps // 4) * 128 + 24.0 + 0.1 * halo)
+            key = (cost, -TW)
+            if best is None or key < best[0]:
+                best = (key, (TH, TW, 1))
+    return best[1] if best else None
 
 
 @lru_cache(maxsize=None)

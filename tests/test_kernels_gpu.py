@@ -915,6 +915,65 @@ def test_weight_gradient_16x16x32_with_dy_by_lds_dma(ops, shape, tile):
 
 
 @pytest.mark.parametrize("shape,tile", [
+    ((3, 32, 32, 80, 300, 1), None),          # the first layer's shape with the tile its rule picks (8 x 16: four k-steps, one per wave)
+    ((2, 32, 32, 19, 45, 1), None),           # the rule's tile on an odd image (10 x 12: ragged edges, DMA chunks straddling tile rows)
+    ((2, 32, 32, 19, 45, 1), (14, 8)),        # the general kernel's tile: 112 pixels = 3.5 k-steps
+    ((2, 64, 32, 13, 29, 1), (2, 24)),        # two input-channel groups, 48 pixels: two waves have no k-step
+    ((2, 32, 32, 3, 5, 1), (4, 16)),          # an image smaller than one tile
+    ((2, 32, 32, 40, 150, 2), (4, 10)),       # stride 2
+])
+def test_weight_gradient_16x16x32_32_channel_groups(ops, shape, tile):
+    """conv_wgrad_wm16_kernel<., C32> (csrc/conv_wgrad_wm16.hip): the layout for 32-channel groups - the first layer's weight gradients
+    whenever dY is an f16 pair tensor.  Every wave holds the whole 9 x 32 x 32 tile, the four waves split the 32-pixel k-steps of a
+    region and write four slabs per block; dY by LDS DMA in chunks of 8 pixels.  Against conv_wgrad_split_kernel (SPK_C32M16=0) and the
+    fp64 gradient, with and without the fused BatchNorm + ReLU on X and with accumulation (reference: scripts/model.py:41-44 nn.Conv2d
+    under scripts/train_resnet.py:327)."""
+    from helpers import encode_pairs, sigma_of, slot
+    from pytorch_kaldi_resnet_amd import tiling
+    B, Cin, Cout, H, Wd, stride = shape
+    OH, OW = ops.conv_out_hw(H, Wd, 3, stride)
+    key = (OH, OW, Cin, Cout, 3, stride)
+    old_c32, old_split = ops.C32M16, ops.SPLIT
+    if tile is not None:
+        tiling.FORCE_WGRAD_C32M16[key] = (tile[0], tile[1], 1)
+    ops.SPLIT = ops.MFMA_MODES["f16x3"]
+    try:
+        x = rnd(41, B, H, Wd, Cin).cuda()
+        dy = (rnd(42, B, OH, OW, Cout, scale=3e-4) * (1 + 50 * (rnd(43, B, OH, OW, 1) > 0.97))).cuda()
+        sc, sh = rnd(44, Cin, scale=0.4, shift=1.0).cuda(), rnd(45, Cin, scale=0.3).cuda()
+        dy_amax = ops.absmax_into(dy, slot())
+        x_amax = ops.absmax_into(x, slot())
+        xa_amax = ops.absmax_into(torch.relu(x * sc + sh), slot())
+        dy_p = encode_pairs(dy.cpu(), sigma_of(dy_amax)).cuda()
+        res = {}
+        for m16 in (True, False):
+            ops.C32M16 = m16
+            dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw, 3, stride, dy_amax=dy_amax, x_amax=x_amax, dy_presplit=True)
+            dw2 = torch.full((Cout, Cin, 3, 3), 0.25, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw2, 3, stride, in_affine=(sc, sh), accumulate=True, dy_amax=dy_amax, x_amax=xa_amax, dy_presplit=True)
+            dw3 = torch.empty(Cout, Cin, 3, 3, device="cuda")
+            ops.conv_wgrad(x, dy_p, dw3, 3, stride, dy_amax=dy_amax, x_amax=x_amax, dy_presplit=True)
+            res[m16] = (dw, dw2, dw3)
+        torch.cuda.synchronize()
+        assert torch.equal(res[True][0], res[True][2]), "not deterministic"
+        xc, dc = x.cpu().permute(0, 3, 1, 2).double(), dy.cpu().permute(0, 3, 1, 2).double()
+        ref = torch.nn.grad.conv2d_weight(xc, (Cout, Cin, 3, 3), dc, stride=stride, padding=1)
+        xa = torch.relu(xc * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1))
+        ref2 = torch.nn.grad.conv2d_weight(xa, (Cout, Cin, 3, 3), dc, stride=stride, padding=1)
+        e16, e32 = [(res[m][0].double().cpu() - ref).norm() / ref.norm() for m in (True, False)]
+        print("shape %s tile %s: |dw - fp64| / |fp64| = %.2e (16x16x32, 32-channel groups)  %.2e (general kernel)" % (shape, tile, e16, e32))
+        assert e16 < 1e-5 and e16 < 2 * e32 + 1e-7, (e16, e32)
+        assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-6 * float(ref.abs().max())
+        d2 = (res[True][1].double().cpu() - 0.25) - ref2
+        assert d2.norm() <= 1e-5 * ref2.norm() + 1.5e-8 * ref2.numel() ** 0.5
+        assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 3e-8
+    finally:
+        ops.C32M16, ops.SPLIT = old_c32, old_split
+        tiling.FORCE_WGRAD_C32M16.pop(key, None)
+
+
+@pytest.mark.parametrize("shape,tile", [
     ((3, 64, 64, 40, 150), (8, 8)),        # the step's own tiles (tile_table.json) ...
     ((3, 128, 128, 20, 75), (4, 16)),
     ((2, 256, 256, 10, 38), (5, 8)),       # ... 40 pixels = 2.5 k-steps: the padded half-step multiplies zeros of dY

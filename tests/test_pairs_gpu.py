@@ -101,12 +101,12 @@ def test_pair_tensor_paths_equal_the_fp32_draw_paths_bit_for_bit(ops, shape):
     assert torch.equal(dx_f, dx_p), "data gradient: pair staging differs from conversion while staging"
     dw_f, dw_p = torch.empty(Cout, Cin, k, k, device="cuda"), torch.empty(Cout, Cin, k, k, device="cuda")
     # (same kernel for both: the 16x16x32 form - csrc/conv_wgrad_wm16.hip - exists for pair tensors only and sums in another order)
-    old_wm16, ops.WM16 = ops.WM16, False
+    old_m16, ops.WM16, ops.C32M16 = (ops.WM16, ops.C32M16), False, False
     try:
         ops.conv_wgrad(x, draw_f, dw_f, k, s, dy_amax=est, x_amax=x_amax)
         ops.conv_wgrad(x, draw_p, dw_p, k, s, dy_amax=est, x_amax=x_amax, dy_presplit=True)
     finally:
-        ops.WM16 = old_wm16
+        ops.WM16, ops.C32M16 = old_m16
     assert torch.equal(dw_f, dw_p), "weight gradient: pair staging differs from conversion while staging"
     ops.conv_wgrad(x, draw_p, dw_p, k, s, dy_amax=est, x_amax=x_amax, dy_presplit=True)      # the default pair path
     assert float((dw_p - dw_f).abs().max()) <= 2e-6 * float(dw_f.abs().max()), "weight gradient: the default pair path"
@@ -136,12 +136,12 @@ def test_pair_tensor_paths_equal_the_fp32_draw_paths_bit_for_bit(ops, shape):
         assert torch.equal(sd_p.cpu().view(torch.int32), encode_pairs(sd_f.cpu(), sig).view(torch.int32))
         # the fused form and the separate pass compute the same draw up to the contraction of the fp32 expression
         assert float((sd_f - draw_f).abs().max()) <= 4e-6 * truth
-        old_wm16, ops.WM16 = ops.WM16, False            # same kernel for both (the 16x16x32 form takes pair tensors only)
+        old_m16, ops.WM16, ops.C32M16 = (ops.WM16, ops.C32M16), False, False      # same kernel for both (the 16x16x32 forms take pair tensors only)
         try:
             ops.conv_wgrad(x, sd_p, dw_p, k, 1, dy_amax=est2, x_amax=x_amax, dy_presplit=True)
             ops.conv_wgrad(x, sd_f, dw_f, k, 1, dy_amax=est2, x_amax=x_amax)
         finally:
-            ops.WM16 = old_wm16
+            ops.WM16, ops.C32M16 = old_m16
         assert torch.equal(dw_f, dw_p)
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B inside the training step on ONE box, alternating runs: the 16x16x32 weight gradient with dY by LDS DMA (csrc/conv_wgrad_wm16.hip)
-# with the conversion of X dealt out in its last k-step (default) / as a pass of its own (variant library cvtpass: tools/variant.sh cvtpass
-# conv_wgrad_wm16.hip -DWM16_CVT_IN_LOOP=0) / against conv_wgrad_wm_kernel (SPK_WM16=0).
+# A/B inside the training step on ONE box, alternating runs, of the 16x16x32 weight gradients with dY by LDS DMA (csrc/conv_wgrad_wm16.hip):
+# SPK_C32M16 = the 32-channel-group layout (first layer) against conv_wgrad_split_kernel; SPK_WM16 = the 2 x 2 layout against conv_wgrad_wm_kernel.
+# WM_AB="name:VAR=val,VAR=val name2:..." overrides the plan.
 D=${1:-gpurun_out/wm_ab}
 mkdir -p $D
 FAST="--steps 20 --warmup 5 --no-cpu-baseline --no-eer --no-fp32-leg --no-f16-window --no-extra"
@@ -23,10 +23,6 @@ for k, v in sorted(((j.get("roofline") or {}).get("all_kernels") or {}).items(),
         print("    %-62s %7.3f ms %3d x %.3f" % (k[:62], v["ms_per_step"], v["launches_per_step"], v["ms_per_step"] / max(1, v["launches_per_step"])))
 PY
 }
-V=pytorch-kaldi-resnet_amd/variants
-one inloop_a SPK_WM16=1
-one cvtpass_a SPK_WM16=1 SPK_LIB=$V/libspkhip_cvtpass.so
-one m32_a SPK_WM16=0
-one inloop_b SPK_WM16=1
-one cvtpass_b SPK_WM16=1 SPK_LIB=$V/libspkhip_cvtpass.so
-one m32_b SPK_WM16=0
+for spec in ${WM_AB:-c32_a:SPK_C32M16=1 split_a:SPK_C32M16=0 c32_b:SPK_C32M16=1 split_b:SPK_C32M16=0}; do
+    one ${spec%%:*} $(echo ${spec#*:} | tr ',' ' ')
+done
