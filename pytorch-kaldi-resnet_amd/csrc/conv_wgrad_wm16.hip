@@ -41,6 +41,21 @@ static __device__ __forceinline__ s16x8 tr_read8w(const unsigned char* p0, const
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __attribute__((aligned(16))) unsigned g_wm16_zero[4];      // what the DMA lanes of pixels outside the image fetch
 
+// X pixel pitch and the pixels of a 32-lane half.  A transposed read is banked per 32-lane half (bank = (address / 4) mod 64): the half
+// reads 8 pixels x 32 bytes (4 lanes x 8 bytes of one 16-channel row tile of one term).  First layout (WM16_ODD_PITCH = 0): pixel pitch 384
+// (192) bytes = 12 (6) x 32 and the half's pixels 0-3 and 8-11 of the k-step - pixel h of the halo starts in 32-byte bank group 4 h mod 8
+// (6 h mod 8, and the second four pixels one tile row further: the same groups again): SQ_LDS_BANK_CONFLICT 9.2e7 of 1.30e8
+// SQ_LDS_IDX_ACTIVE cycles per launch (3.1e7 of 7.2e7 in the 32-channel layout) - every X read took four (two) LDS cycles per half
+// instead of one (profiles/r04_sq_counters/final_kernels_*).  Now: an odd number of 32-byte units per pixel (416 = 13 x 32 bytes; 160 =
+// 5 x 32 in the 32-channel layout) and the half reads 8 CONSECUTIVE tile pixels (lane group kg holds pixels 16 (kg >> 1) + 4 (kg & 1) + q
+// and + 8 of the step; dY chunks follow the same assignment) - one tile row when the tile is 8 or 16 wide: eight different bank groups.
+// (dY keeps its two-way conflict - 8 of the 80 reads of a k-step: both halves of a 16-byte piece cannot be read by one half-wave of
+// lanes that all want the same term.)
+#ifndef WM16_ODD_PITCH
+#define WM16_ODD_PITCH 1
+#endif
+#define WM16_PX_WIDE (WM16_ODD_PITCH ? 416 : 384)       /* X bytes per staged pixel, 2 x 2 wave layout: [2 groups][3-term pitch][32 ch fp16] (+ 32) */
+#define WM16_PX_C32 (WM16_ODD_PITCH ? 160 : 192)        /* ... 32-channel layout: [2 terms][32 ch fp16] (+ 32) */
 #ifndef WM16_CVT_IN_LOOP
 #define WM16_CVT_IN_LOOP 0      // 1: the conversion of the next region's X dealt out between the matrix instructions of the last k-step
 #endif                          //    (built and measured +-0 inside the step - DESIGN.md section 7b; the default is the plain pass after the K loop)
@@ -56,7 +71,7 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     constexpr int NTAPS = 9, KS = 3;
     constexpr int CGL = C32 ? 5 : 6;                      // log2 of the channels per block side
-    constexpr int PX = C32 ? 192 : 2 * 192;               // X bytes per staged pixel: [1 or 2 groups][3-term pitch][32 ch fp16]
+    constexpr int PX = C32 ? WM16_PX_C32 : WM16_PX_WIDE;  // X bytes per staged pixel
     constexpr int QXL = C32 ? 3 : 4;                      // log2 of the threads (float4) per X pixel
     constexpr int PXP = 256 >> QXL;                       // X pixels per staging pass
     constexpr int WM16_NX = C32 ? 6 : 7;                  // X halo float4 per thread: halo_pix <= PXP * WM16_NX (192 / 112 pixels)
@@ -202,8 +217,10 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
     const int kg = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
     const int a_lane = wm * 192 + p4 * 8;                                  // X: [group wm][term][32 ch]: row tile rt at + 32 rt, term s at + 64 s
     // dY: pixels 8 kg + 4 blk + q of the step: chunk 2 kg + blk, slot (2 wn + ct) * 16 + 4 p4 + q (C32: chunk kg, slot 32 blk + 16 ct + 4 p4 + q); term s at + 8 s
-    const int d_lane = (C32 ? kg : 2 * kg) * 1024 + wn * 512 + p4 * 64 + q * 16;
-    constexpr int D_STEP = C32 ? 4096 : 8192, D_BLK = C32 ? 512 : 1024;
+    // (WM16_ODD_PITCH: pixels 16 (kg >> 1) + 8 blk + 4 (kg & 1) + q: chunk 4 (kg >> 1) + 2 blk + (kg & 1); C32: chunk 2 (kg >> 1) + blk, slot 32 (kg & 1) + ...)
+    const int d_lane = (WM16_ODD_PITCH ? (C32 ? 2 * (kg >> 1) * 1024 + (kg & 1) * 512 : (4 * (kg >> 1) + (kg & 1)) * 1024) : (C32 ? kg : 2 * kg) * 1024) +
+                       wn * 512 + p4 * 64 + q * 16;
+    constexpr int D_STEP = C32 ? 4096 : 8192, D_BLK = WM16_ODD_PITCH ? (C32 ? 1024 : 2048) : (C32 ? 512 : 1024);
 
     int region = g, buf = 0;
     if (region < a.nregions) {
@@ -236,7 +253,7 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
             int xa[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const int pix = j * 32 + 8 * kg + 4 * blk + q;
+                const int pix = j * 32 + (WM16_ODD_PITCH ? 16 * (kg >> 1) + 8 * blk + 4 * (kg & 1) : 8 * kg + 4 * blk) + q;
                 const int pc = pix < npix ? pix : npix - 1;
                 const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
                 const int lx = pc - ly * a.TW;
@@ -344,7 +361,7 @@ int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st) {
                 a.halo_h, a.halo_w);
     SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
                 "spk_conv_wgrad(2x2 waves, 16x16x32): an image exceeds 32-bit byte offsets");
-    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 384 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 256;
+    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_WIDE + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 256;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
     if (a.flags & SPK_IN_AFFINE_RELU) hipLaunchKernelGGL(conv_wgrad_wm16_kernel<1>, grid, dim3(256), lds_bytes, st, a);
@@ -361,7 +378,7 @@ int spk_launch_wgrad_c32m16(const WgradArgs& a, hipStream_t st) {
                 a.halo_h, a.halo_w);
     SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
                 "spk_conv_wgrad(32-channel groups, 16x16x32): an image exceeds 32-bit byte offsets");
-    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * 192 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 128;
+    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_C32 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 128;
     if (lds_bytes < 3 * 12 * 64 * 16) lds_bytes = 3 * 12 * 64 * 16;      // the fold of the four waves' tiles at the end of a block
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(32-channel groups, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / 32));

@@ -648,7 +648,7 @@ def conv_wgrad(x, dy, dw, ksize, stride, in_affine=None, accumulate=False, dy_am
     # 3x3, f16x3: 2 input-channel groups x 2 output-channel groups of waves (csrc/conv_wgrad_wm.hip)
     wm = (GROUPED_3X3 and not wgws and not wgp and split == 3 and ksize == 3 and WN == 2 and Cin % 64 == 0 and Cout % 64 == 0
           and halo <= 112 and TH * TW <= 64 and halo * 384 + -(-(TH * TW) // 16) * 16 * 448 <= 80 * 1024)
-    wm16 = wm and WM16 and dy_presplit and halo * 384 + 2 * -(-(TH * TW) // 32) * 32 * 256 <= 80 * 1024
+    wm16 = wm and WM16 and dy_presplit and halo * 416 + 2 * -(-(TH * TW) // 32) * 32 * 256 <= 80 * 1024     # X pixel pitch 416 B (csrc/conv_wgrad_wm16.hip)
     # ... and the same kernel in its 32-channel-group layout (the first layer): four waves split the k-steps and fold at the end of the block
     c32m16 = (C32M16 and not wm and not wgws and not wgp and split == 3 and ksize == 3 and WN == 1 and dy_presplit and halo <= 192
               and halo * 192 + 2 * -(-(TH * TW) // 32) * 32 * 128 <= 80 * 1024)
