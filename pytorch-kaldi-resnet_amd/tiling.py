@@ -258,8 +258,8 @@ def c32m16_tile(OH, OW, Cin, Cout, ksize, stride):
 @lru_cache(maxsize=None)
 def wgrad_tile_c32m16(OH, OW, ksize, stride):
     """Tile (TH, TW, WN = 1) for conv_wgrad_wm16_kernel<., C32> (csrc/conv_wgrad_wm16.hip): k-steps of 32 pixels dealt to four waves, so a
-    region costs ceil(steps / 4) step times; halo <= 192 pixels (six 32-pixel staging passes); X 192 B and two dY buffers of 128 B per
-    pixel within 80 KB (two blocks per CU).  Ties go to the wider tile (longer contiguous runs for the DMA chunks of 8 pixels)."""
+    region costs ceil(steps / 4) step times; halo <= 192 pixels (six 32-pixel staging passes); X and two dY buffers of 128 B per
+    pixel within 80 KB (two blocks per CU; X priced at 192 B per pixel - the kernel's odd pitch is 160 B, the bound stays on the safe side).  Ties go to the wider tile (longer contiguous runs for the DMA chunks of 8 pixels)."""
     best = None
     for TH in range(1, OH + 1):
         for TW in range(2, OW + 2, 2):
