@@ -342,3 +342,25 @@ def test_operand_modes_are_declared():
         assert ops.packed_numel(w) == w.numel() + 4 and ops.packed_numel(w, bwd=True) == w.numel() * 3 // 2
     finally:
         ops.SPLIT, ops.SPLIT_BWD = old
+
+
+def test_lds_bank_model_of_the_weight_gradient_x_image():
+    """tools/lds_bank_model.py restates the lane -> LDS address formulas of conv_wgrad_wm16_kernel's transposed reads and the bank
+    rule of ds_read_b64_tr_b16 (per 32-lane half, 64 banks of 4 bytes).  The kernel's X layout must keep the tiles of the training
+    step that are 8 or 16 pixels wide free of bank conflicts on their X reads (the first layout - pixel pitch 384 / 192 bytes - read
+    them four / two deep: SQ_LDS_BANK_CONFLICT 9.2e7 of 1.30e8 LDS cycles per launch, profiles/r04_sq_counters), and the constants the
+    model uses must be the ones in the source."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(os.path.dirname(__file__), "..", "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = open(os.path.join(os.path.dirname(__file__), "..", "pytorch-kaldi-resnet_amd", "csrc", "conv_wgrad_wm16.hip")).read()
+    assert "#define WM16_PX_WIDE (WM16_ODD_PITCH ? 416 : 384)" in src and "#define WM16_PX_C32 (WM16_ODD_PITCH ? 160 : 192)" in src
+    assert "#define WM16_ODD_PITCH 1" in src
+    for TH, TW, c32 in ((8, 8, False), (4, 16, False), (8, 16, True)):
+        for j in range(-(-(TH * TW) // 32)):
+            for t in range(9):
+                assert m.x_read_cycles(TH, TW, 1, True, c32, j, (t // 3, t % 3)) == 4          # one cycle per half, two reads
+        assert m.x_read_cycles(TH, TW, 1, False, c32) == (8 if c32 else 16)                      # the first layout: two / four deep
+    assert m.dy_read_cycles(True, False) == 8 and m.dy_read_cycles(True, True) == 8              # dY: two deep by construction of the DMA image
+    assert abs(m.kstep_ratio(8, 8, 1, False, False) - 3.8) < 1e-9 and abs(m.kstep_ratio(8, 8, 1, True, False) - 1.1) < 1e-9
