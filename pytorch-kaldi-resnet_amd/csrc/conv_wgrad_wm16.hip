@@ -54,6 +54,14 @@ __device__ __attribute__((aligned(16))) unsigned g_wm16_zero[4];      // what th
 #ifndef WM16_ODD_PITCH
 #define WM16_ODD_PITCH 1
 #endif
+// WM16_ROW_SKEW (bytes added per halo ROW, default 0 = not built into the library): tiles that are not 8 or 16 pixels wide - 10 x 6 in the
+// 256-channel layer - put the 8 consecutive pixels of a half-wave on two tile rows of a halo 8 pixels wide, where two of them meet occupied
+// bank groups whatever the pixel pitch; 192 bytes per halo row move them onto the two groups a 6-pixel row leaves free
+// (tools/lds_bank_model.py: 1.9 -> 1.0 x the conflict-free cycles on 10 x 6, 1.0 stays 1.0 on 8 x 8 and 4 x 16).  A variant build for the
+// A/B (tools/variant.sh skew conv_wgrad_wm16.hip -DWM16_ROW_SKEW=192); the default code is unchanged by the macro.
+#ifndef WM16_ROW_SKEW
+#define WM16_ROW_SKEW 0
+#endif
 #define WM16_PX_WIDE (WM16_ODD_PITCH ? 416 : 384)       /* X bytes per staged pixel, 2 x 2 wave layout: [2 groups][3-term pitch][32 ch fp16] (+ 32) */
 #define WM16_PX_C32 (WM16_ODD_PITCH ? 160 : 192)        /* ... 32-channel layout: [2 terms][32 ch fp16] (+ 32) */
 #ifndef WM16_CVT_IN_LOOP
@@ -100,7 +108,7 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
     const int nsteps = (npix + 31) >> 5;                  // k-steps of 32 pixels; the padding pixels of dY are zero
     const int nchunks = nsteps << (5 - CPL);              // DMA chunks (1024 bytes: 4 pixels x 64 channels or 8 x 32) of a dY buffer
     unsigned char* xs = ldsb;
-    unsigned char* dys = ldsb + halo_pix * PX;            // two buffers of nchunks * 1024 bytes
+    unsigned char* dys = ldsb + halo_pix * PX + a.halo_h * WM16_ROW_SKEW;      // two buffers of nchunks * 1024 bytes
     const int dbuf = nchunks << 10;
     const float sig_x = spk_sigma_from_amax_bits(*a.x_amax);
     const float sig_d = spk_sigma_from_amax_bits(*a.dy_amax);
@@ -203,7 +211,9 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
         for (int u = 0; u < WM16_NX; ++u) {
             const int p = (tid >> QXL) + PXP * u;
             if (p < halo_pix) {
-                uint2* dst = (uint2*)(xs + p * PX + (q16 >> 3) * 192) + (q16 & 7);
+                unsigned char* pp = xs + p * PX + (q16 >> 3) * 192;
+                if constexpr (WM16_ROW_SKEW != 0) pp += (int)__umulhi((unsigned)p, a.halo_w_magic) * WM16_ROW_SKEW;
+                uint2* dst = (uint2*)pp + (q16 & 7);
                 uint2 t0, t1;
                 spk_pair_unpack(px[u], t0, t1);
                 dst[0] = t0;
@@ -257,11 +267,11 @@ static __device__ __forceinline__ void wgrad_m16_body(const WgradArgs& a) {
                 const int pc = pix < npix ? pix : npix - 1;
                 const int ly = (int)__umulhi((unsigned)pc, a.tw_magic);
                 const int lx = pc - ly * a.TW;
-                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + a_lane;
+                xa[blk] = ((ly * a.S) * a.halo_w + lx * a.S) * PX + (ly * a.S) * WM16_ROW_SKEW + a_lane;
             }
             s16x8 af[2][2];                               // [term][row tile]
             auto load_a = [&](int s, int t) {
-                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX + s * 64;
+                const int toff = ((t / KS) * a.halo_w + (t % KS)) * PX + (t / KS) * WM16_ROW_SKEW + s * 64;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) af[s][rt] = tr_read8w(xs + xa[0] + toff + rt * 32, xs + xa[1] + toff + rt * 32);
             };
@@ -361,7 +371,7 @@ int spk_launch_wgrad_wm16(const WgradArgs& a, hipStream_t st) {
                 a.halo_h, a.halo_w);
     SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
                 "spk_conv_wgrad(2x2 waves, 16x16x32): an image exceeds 32-bit byte offsets");
-    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_WIDE + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 256;
+    const size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_WIDE + (size_t)a.halo_h * WM16_ROW_SKEW + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 256;
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(2x2 waves, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 64) * (a.Cout / 64));
     if (a.flags & SPK_IN_AFFINE_RELU) hipLaunchKernelGGL(conv_wgrad_wm16_kernel<1>, grid, dim3(256), lds_bytes, st, a);
@@ -378,7 +388,7 @@ int spk_launch_wgrad_c32m16(const WgradArgs& a, hipStream_t st) {
                 a.halo_h, a.halo_w);
     SPK_REQUIRE((long long)a.OH * a.OW * a.Cout * 4 < 0x7fffffffLL && (long long)a.IH * a.IW * a.Cin * 4 < 0x7fffffffLL,
                 "spk_conv_wgrad(32-channel groups, 16x16x32): an image exceeds 32-bit byte offsets");
-    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_C32 + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 128;
+    size_t lds_bytes = (size_t)a.halo_h * a.halo_w * WM16_PX_C32 + (size_t)a.halo_h * WM16_ROW_SKEW + 2 * (size_t)(((a.TH * a.TW + 31) >> 5) << 5) * 128;
     if (lds_bytes < 3 * 12 * 64 * 16) lds_bytes = 3 * 12 * 64 * 16;      // the fold of the four waves' tiles at the end of a block
     SPK_REQUIRE(lds_bytes <= 160 * 1024, "spk_conv_wgrad(32-channel groups, 16x16x32): tile %dx%d needs %zu B of LDS", a.TH, a.TW, lds_bytes);
     dim3 grid(a.nsplit * (a.Cin / 32) * (a.Cout / 32));
