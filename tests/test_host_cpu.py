@@ -364,3 +364,41 @@ def test_lds_bank_model_of_the_weight_gradient_x_image():
         assert m.x_read_cycles(TH, TW, 1, False, c32) == (8 if c32 else 16)                      # the first layout: two / four deep
     assert m.dy_read_cycles(True, False) == 8 and m.dy_read_cycles(True, True) == 8              # dY: two deep by construction of the DMA image
     assert abs(m.kstep_ratio(8, 8, 1, False, False) - 3.8) < 1e-9 and abs(m.kstep_ratio(8, 8, 1, True, False) - 1.1) < 1e-9
+
+
+def test_lds_bank_model_of_the_pipelined_convolution():
+    """The same tool restates conv_pipe_kernel's 16x16x32 form: the lane -> LDS address of an A-fragment ds_read_b128 (lbase[] of
+    conv_body, pix_of_row16, pixel pitch 80 bytes) and of a staging store.  A row tile of 16 consecutive pixels whose pixels sit in
+    two tile rows reads two deep (the halo's two extra pixels shift the second row by 10 granules, so pixel 15 lands on pixel 1's
+    bank group): 1.79 x the conflict-free cycles on 20 x 19 tiles, 1.38 x on 10 x 38 - with the staging stores and the epilogue slab
+    the model lands within 1 / 7 / 3 % of the measured SQ_INSTS_LDS / SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT of a launch
+    (profiles/r04_sq_counters/final_kernels_after_odd_pitch_lds_vmem.md).  Six more granules per halo row (96 bytes: shift = 16
+    granules) is the only row pad below 16 that removes the read conflicts; the constants the model uses must be the source's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(os.path.dirname(__file__), "..", "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = open(os.path.join(os.path.dirname(__file__), "..", "pytorch-kaldi-resnet_amd", "csrc", "conv_kernel.h")).read()
+    assert "static constexpr int LP4 = SPLIT ? (NTERM * CK * 2 + 16) / 16 : 9;" in src and "#define SPK_SPLIT_CK 16" in src     # 2 * 16 * 2 + 16 = 80 bytes
+    assert "const int q = (row + 12) & 15;" in src and "return ((q & 7) << 1) | (q >> 3);" in src
+    assert "lbase[i] = ((ly * a.IS) * a.halo_w + lx * a.IS) * LP4 + 2 * ((lane >> 4) & 1);" in src
+    assert "uint2* dst = (uint2*)plane + p * (LP4 * 2) + (qd >> 1) * 4 + (qd & 1);" in src
+    assert m.PIPE_LP4 == 5 and sorted(m.pix_of_row16(r) for r in range(16)) == list(range(16))
+    # the tiles the step launches this kernel with are the ones the model walks
+    import pytorch_kaldi_resnet_amd  # noqa: F401
+    from pytorch_kaldi_resnet_amd import tiling
+    for (OH, OW, C), (_, _, TH, TW, cin, blocks) in zip(((40, 150, 64), (20, 75, 128), (10, 38, 256)), m.PIPE_LAUNCHES):
+        assert tiling.conv_tile(OH, OW, 1, 3, 3, 9, C, mode=0, split=3) == (TH, TW, 3, 2) and cin == C
+        assert blocks == 256 * -(-OH // TH) * -(-OW // TW) * (C // 64)
+    # a row tile inside one tile row is conflict-free, one that straddles two rows is two deep in every lane group
+    assert m.pipe_a_read_cycles(20, 19, 1, 0) == 4 and m.pipe_a_read_cycles(20, 19, 1, 1) == 8
+    assert abs(m.pipe_a_read_ratio(20, 19) - 1.7917) < 1e-3 and abs(m.pipe_a_read_ratio(10, 38) - 1.375) < 1e-9
+    assert [p for p in range(16) if m.pipe_a_read_ratio(20, 19, row_pad=p) < 1.1] == [6]
+    assert [p for p in range(16) if m.pipe_a_read_ratio(10, 38, row_pad=p) < 1.1] == [6]
+    assert m.pipe_stage_write_cycles() == 16                                  # 80-byte pixels: 4 pixels of a 16-lane group, two deep
+    insts, cycles, conflicts, read_conf = m.pipe_launch_model()
+    assert abs(insts / 5.288e6 - 1) < 0.02 and abs(cycles / 4.007e7 - 1) < 0.08 and abs(conflicts / 1.654e7 - 1) < 0.04
+    assert 0.55 < read_conf / conflicts < 0.65                                 # the A reads are six tenths of the conflict cycles
+    # the padded halo rows still fit two blocks per CU (2 slots + the dump pixel <= 80 KB)
+    for TH, TW in ((20, 19), (10, 38)):
+        assert 2 * (TH + 2) * ((TW + 2) * 80 + 96) + 80 <= 80 * 1024
