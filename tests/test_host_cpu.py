@@ -399,6 +399,13 @@ def test_lds_bank_model_of_the_pipelined_convolution():
     insts, cycles, conflicts, read_conf = m.pipe_launch_model()
     assert abs(insts / 5.288e6 - 1) < 0.02 and abs(cycles / 4.007e7 - 1) < 0.08 and abs(conflicts / 1.654e7 - 1) < 0.04
     assert 0.55 < read_conf / conflicts < 0.65                                 # the A reads are six tenths of the conflict cycles
-    # the padded halo rows still fit two blocks per CU (2 slots + the dump pixel <= 80 KB)
+    # the padded halo rows still fit two blocks per CU (2 slots + the dump pixel <= 80 KB), and the address arithmetic of the prepared
+    # variant (tools/patches/pipe_row_pad.patch: store, read base, tap offsets) is consistent with and without the pad
     for TH, TW in ((20, 19), (10, 38)):
         assert 2 * (TH + 2) * ((TW + 2) * 80 + 96) + 80 <= 80 * 1024
+        assert m.pipe_row_pad_consistent(TH, TW, 1, 0) == (TH + 2) * (TW + 2) * 80
+        assert m.pipe_row_pad_consistent(TH, TW, 1, 6) == (TH + 2) * ((TW + 2) * 80 + 96)
+    patch = open(os.path.join(os.path.dirname(__file__), "..", "tools", "patches", "pipe_row_pad.patch")).read()
+    for line in ("lbase[i] += ly * a.IS * PIPE_ROW_PAD;", "dst += (int)__umulhi((unsigned)p, a.halo_w_magic) * (PIPE_ROW_PAD * 2);",
+                 "a.tap_off[t] += (tap_dy[t] - mindy) * PIPE_ROW_PAD;", "lds2 += (size_t)2 * a.halo_h * PIPE_ROW_PAD * 16;"):
+        assert line in patch

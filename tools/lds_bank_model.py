@@ -170,6 +170,35 @@ def pipe_launch_model(row_pad=0):
     return insts / n, cycles / n, conflicts / n, reads_conf / n
 
 
+def pipe_row_pad_consistent(TH, TW, IS, row_pad):
+    """Address arithmetic of tools/patches/pipe_row_pad.patch, emulated: the staging store of (halo pixel, 8-channel half, term) and
+    the A-fragment read of (tile pixel, tap, half, term) must meet on the same 16-byte granule, every granule must hold one item,
+    and everything must stay inside the slot.  -> bytes of one LDS slot."""
+    halo_w, halo_h = (TW - 1) * IS + 3, (TH - 1) * IS + 3
+    magic = (0x100000000 + halo_w - 1) // halo_w                       # ConvArgs::halo_w_magic
+    plane4 = halo_h * halo_w * PIPE_LP4 + halo_h * row_pad
+    written = {}
+    for p in range(halo_h * halo_w):
+        hy = (p * magic) >> 32                                         # __umulhi(p, halo_w_magic)
+        assert hy == p // halo_w
+        for qd in range(4):
+            for term in range(2):
+                u2 = p * (PIPE_LP4 * 2) + (qd >> 1) * 4 + (qd & 1) + hy * (row_pad * 2) + 2 * term        # store_pair_q (uint2 units)
+                assert u2 // 2 < plane4
+                written.setdefault(u2 // 2, set()).add((p, qd >> 1, term))
+    assert all(len(v) == 1 for v in written.values())
+    for q in range(TH * TW):
+        ly, lx = divmod(q, TW)
+        for half in range(2):
+            lbase = ((ly * IS) * halo_w + lx * IS) * PIPE_LP4 + 2 * half + ly * IS * row_pad
+            for dy in range(3):
+                for dx in range(3):
+                    tap_off = (dy * halo_w + dx) * PIPE_LP4 + dy * row_pad                                  # launcher
+                    for term in range(2):
+                        assert written.get(lbase + tap_off + term) == {((ly * IS + dy) * halo_w + lx * IS + dx, half, term)}
+    return plane4 * 16
+
+
 STEP_TILES = [("64 ch 40x150", 8, 8, 1, False), ("128 ch 20x75", 4, 16, 1, False), ("256 ch 10x38", 10, 6, 1, False),
               ("32 ch 80x300 (32-channel layout)", 8, 16, 1, True)]
 
